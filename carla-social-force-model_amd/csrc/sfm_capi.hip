@@ -1,0 +1,514 @@
+// sfm_capi.hip -- host side of libsfm_hip.so: the C ABI declared in include/sfm_hip.h.
+// Owns the device buffers (fp32, packed for 16-B/lane streaming), folds the TOML parameters into kernel
+// constants, launches the fused tick, and moves results back.  No torch types; a hipStream_t comes in as
+// a void*.
+#include "sfm_device.h"
+#include "sfm_hip.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace sfm {
+hipError_t launch_tick(int ipw, bool z3, bool rad, const TickArgs& a, hipStream_t st);
+hipError_t launch_arrived(const float4* pk, const float4* own, int N, float thr2, uint8_t* mask, hipStream_t st);
+}  // namespace sfm
+
+using namespace sfm;
+
+static thread_local std::string g_create_error;
+
+struct DevGeo {
+    int* off = nullptr;
+    float2* pts = nullptr;
+    float4* ctr = nullptr;
+    int K = 0;
+    int P = 0;
+};
+
+struct SfmHandle {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    SfmParams prm{};
+    std::string err;
+
+    int N = 0, N_pad = 0, cap = 0;        // cap = allocated records
+    bool z3 = false, rad = false;
+    int i_begin = 0, i_end = 0;
+    int cur = 0;
+    float4* pk[2] = {nullptr, nullptr};
+    float2* zv[2] = {nullptr, nullptr};
+    float4* own = nullptr;
+    float* radius = nullptr;
+    uint8_t* crossing = nullptr;
+    uint8_t* arrived = nullptr;
+    uint32_t* draws = nullptr;
+    float* rec = nullptr;                 // [6][3][N]
+    bool rec_valid = false;
+    DevGeo borders, statics, dynamics;
+
+    uint32_t seed = 0;
+    float world_side = 0.f, arrive_thr = 2.0f;
+
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int timed_ticks = 0, timed_launches = 0;
+    bool timing_valid = false;
+    int ipw_last = 0;
+    int ipw_override = 0;
+    char variant[64] = "none";
+};
+
+#define HIP_TRY(h, call)                                                                           \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);                          \
+            return SFM_ERR_HIP;                                                                    \
+        }                                                                                          \
+    } while (0)
+
+static int fail(SfmHandle* h, int code, const char* msg) {
+    if (h) h->err = msg; else g_create_error = msg;
+    return code;
+}
+
+static int bind(SfmHandle* h) {
+    if (!h) return SFM_ERR_INVALID;
+    hipError_t e = hipSetDevice(h->device);
+    if (e != hipSuccess) { h->err = std::string("hipSetDevice: ") + hipGetErrorString(e); return SFM_ERR_HIP; }
+    return SFM_OK;
+}
+
+template <typename T>
+static hipError_t dev_realloc(T*& p, size_t count) {
+    if (p) { hipError_t e = hipFree(p); p = nullptr; if (e != hipSuccess) return e; }
+    if (count == 0) return hipSuccess;
+    return hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
+}
+
+static IxConst fold(const SfmInteraction& s) {
+    const double log2e = 1.4426950408889634;
+    IxConst c{};
+    c.lam = (float)s.lambda;
+    c.eg = (float)((double)s.epsilon * (double)s.gamma);
+    c.c1 = (float)(-log2e / (double)s.gamma);
+    c.k1 = (float)(-((double)s.n_prime * s.gamma) * ((double)s.n_prime * s.gamma) * log2e);
+    c.k2 = (float)(-((double)s.n * s.gamma) * ((double)s.n * s.gamma) * log2e);
+    c.negA = (float)(-(double)s.A);
+    c.thr2 = (float)((double)s.perception_threshold * (double)s.perception_threshold);
+    return c;
+}
+
+static int check_params(const SfmParams* p, const char** why) {
+    if (!p) { *why = "params is NULL"; return 0; }
+    if (!(p->step_length > 0.f)) { *why = "step_length must be > 0"; return 0; }
+    if (!(p->tau > 0.f)) { *why = "tau must be > 0"; return 0; }
+    if (p->enabled[SFM_FORCE_PEDESTRIAN] && !(p->pedestrian.gamma != 0.f)) { *why = "pedestrian.gamma is 0"; return 0; }
+    if (p->enabled[SFM_FORCE_BORDER] && !(p->border_b != 0.f)) { *why = "border_force.b is 0"; return 0; }
+    return 1;
+}
+
+extern "C" {
+
+int sfm_abi_version(void) { return SFM_ABI_VERSION; }
+
+int sfm_create(const SfmParams* params, int device_id, SfmHandle** out) {
+    if (!out) return fail(nullptr, SFM_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    const char* why = nullptr;
+    if (!check_params(params, &why)) return fail(nullptr, SFM_ERR_INVALID, why);
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) return fail(nullptr, SFM_ERR_NO_DEVICE, "no HIP device visible (libsfm_hip needs an MI355X)");
+    if (device_id < 0 || device_id >= ndev) return fail(nullptr, SFM_ERR_INVALID, "device_id out of range");
+    e = hipSetDevice(device_id);
+    if (e != hipSuccess) return fail(nullptr, SFM_ERR_HIP, hipGetErrorString(e));
+    SfmHandle* h = new SfmHandle();
+    h->device = device_id;
+    h->prm = *params;
+    if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
+        delete h;
+        return fail(nullptr, SFM_ERR_HIP, "hipEventCreate failed");
+    }
+    const char* ov = getenv("SFM_IPW");
+    if (ov) h->ipw_override = atoi(ov);
+    *out = h;
+    return SFM_OK;
+}
+
+static void free_geo(DevGeo& g) {
+    if (g.off) hipFree(g.off);
+    if (g.pts) hipFree(g.pts);
+    if (g.ctr) hipFree(g.ctr);
+    g = DevGeo();
+}
+
+int sfm_destroy(SfmHandle* h) {
+    if (!h) return SFM_OK;
+    hipSetDevice(h->device);
+    hipStreamSynchronize(h->stream);
+    for (int b = 0; b < 2; ++b) { if (h->pk[b]) hipFree(h->pk[b]); if (h->zv[b]) hipFree(h->zv[b]); }
+    if (h->own) hipFree(h->own);
+    if (h->radius) hipFree(h->radius);
+    if (h->crossing) hipFree(h->crossing);
+    if (h->arrived) hipFree(h->arrived);
+    if (h->draws) hipFree(h->draws);
+    if (h->rec) hipFree(h->rec);
+    free_geo(h->borders); free_geo(h->statics); free_geo(h->dynamics);
+    if (h->ev0) hipEventDestroy(h->ev0);
+    if (h->ev1) hipEventDestroy(h->ev1);
+    delete h;
+    return SFM_OK;
+}
+
+int sfm_set_params(SfmHandle* h, const SfmParams* params) {
+    if (!h) return SFM_ERR_INVALID;
+    const char* why = nullptr;
+    if (!check_params(params, &why)) return fail(h, SFM_ERR_INVALID, why);
+    h->prm = *params;
+    return SFM_OK;
+}
+
+int sfm_set_stream(SfmHandle* h, void* hip_stream) {
+    if (!h) return SFM_ERR_INVALID;
+    h->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    return SFM_OK;
+}
+
+// Upload one CSR geometry set. ctr4 holds the 4 floats per polyline the kernels want.
+static int set_geo(SfmHandle* h, DevGeo& g, int K, const int32_t* offsets, const float* px, const float* py,
+                   const std::vector<float4>& ctr4) {
+    int rc = bind(h);
+    if (rc) return rc;
+    if (K < 0) return fail(h, SFM_ERR_INVALID, "negative polyline count");
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (K == 0) { free_geo(g); return SFM_OK; }
+    if (!offsets) return fail(h, SFM_ERR_INVALID, "offsets is NULL");
+    if (offsets[0] != 0) return fail(h, SFM_ERR_INVALID, "offsets[0] must be 0");
+    for (int k = 0; k < K; ++k)
+        if (offsets[k + 1] < offsets[k]) return fail(h, SFM_ERR_INVALID, "offsets must be non-decreasing");
+    const int P = offsets[K];
+    if (P > 0 && (!px || !py)) return fail(h, SFM_ERR_INVALID, "point arrays are NULL");
+    std::vector<float2> pts((size_t)P);
+    for (int p = 0; p < P; ++p) pts[p] = make_float2(px[p], py[p]);
+    HIP_TRY(h, dev_realloc(g.off, (size_t)K + 1));
+    HIP_TRY(h, dev_realloc(g.pts, (size_t)(P > 0 ? P : 1)));
+    HIP_TRY(h, dev_realloc(g.ctr, (size_t)K));
+    HIP_TRY(h, hipMemcpy(g.off, offsets, sizeof(int) * ((size_t)K + 1), hipMemcpyHostToDevice));
+    if (P > 0) HIP_TRY(h, hipMemcpy(g.pts, pts.data(), sizeof(float2) * (size_t)P, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(g.ctr, ctr4.data(), sizeof(float4) * (size_t)K, hipMemcpyHostToDevice));
+    g.K = K;
+    g.P = P;
+    return SFM_OK;
+}
+
+int sfm_set_borders(SfmHandle* h, int K, const int32_t* offsets, const float* px, const float* py,
+                    const float* cx, const float* cy, const float* cull_len) {
+    if (!h) return SFM_ERR_INVALID;
+    if (K > 0 && (!cx || !cy || !cull_len)) return fail(h, SFM_ERR_INVALID, "border centre/length arrays are NULL");
+    std::vector<float4> c4((size_t)(K > 0 ? K : 0));
+    for (int k = 0; k < K; ++k)
+        c4[k] = make_float4(cx[k], cy[k], (float)((double)cull_len[k] * (double)cull_len[k]), 0.f);
+    return set_geo(h, h->borders, K, offsets, px, py, c4);
+}
+
+int sfm_set_static_obstacles(SfmHandle* h, int M, const int32_t* offsets, const float* px, const float* py,
+                             const float* cx, const float* cy) {
+    if (!h) return SFM_ERR_INVALID;
+    if (M > 0 && (!cx || !cy)) return fail(h, SFM_ERR_INVALID, "obstacle centre arrays are NULL");
+    std::vector<float4> c4((size_t)(M > 0 ? M : 0));
+    for (int k = 0; k < M; ++k) c4[k] = make_float4(cx[k], cy[k], 0.f, 0.f);
+    return set_geo(h, h->statics, M, offsets, px, py, c4);
+}
+
+int sfm_set_dynamic_obstacles(SfmHandle* h, int M, const int32_t* offsets, const float* px, const float* py,
+                              const float* cx, const float* cy, const float* vx, const float* vy) {
+    if (!h) return SFM_ERR_INVALID;
+    if (M > 0 && (!cx || !cy)) return fail(h, SFM_ERR_INVALID, "obstacle centre arrays are NULL");
+    std::vector<float4> c4((size_t)(M > 0 ? M : 0));
+    for (int k = 0; k < M; ++k)       // velocities default to 0 like ObstacleForce (forces.py:212-213)
+        c4[k] = make_float4(cx[k], cy[k], vx ? vx[k] : 0.f, vy ? vy[k] : 0.f);
+    return set_geo(h, h->dynamics, M, offsets, px, py, c4);
+}
+
+int sfm_upload_state(SfmHandle* h, int N, const float* x, const float* y, const float* z, const float* vx,
+                     const float* vy, const float* vz, const float* wx, const float* wy,
+                     const float* target_speed, const float* radius, const uint8_t* crossing_mask) {
+    int rc = bind(h);
+    if (rc) return rc;
+    if (N < 0) return fail(h, SFM_ERR_INVALID, "N < 0");
+    if (N > 0 && (!x || !y || !vx || !vy || !wx || !wy || !target_speed))
+        return fail(h, SFM_ERR_INVALID, "a required state array is NULL");
+    if ((z == nullptr) != (vz == nullptr)) return fail(h, SFM_ERR_INVALID, "z and vz must be given together");
+    if (h->prm.use_ped_radius && N > 0 && !radius) return fail(h, SFM_ERR_INVALID, "use_ped_radius needs radius");
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const int n_pad = ((N + TILE_J - 1) / TILE_J) * TILE_J;
+    const bool z3 = (z != nullptr);
+    const bool rad = h->prm.use_ped_radius != 0;
+    if (n_pad > h->cap) {
+        for (int b = 0; b < 2; ++b) HIP_TRY(h, dev_realloc(h->pk[b], (size_t)n_pad));
+        for (int b = 0; b < 2; ++b) HIP_TRY(h, dev_realloc(h->zv[b], (size_t)n_pad));
+        HIP_TRY(h, dev_realloc(h->own, (size_t)n_pad));
+        HIP_TRY(h, dev_realloc(h->radius, (size_t)n_pad));
+        HIP_TRY(h, dev_realloc(h->crossing, (size_t)n_pad));
+        HIP_TRY(h, dev_realloc(h->arrived, (size_t)n_pad));
+        HIP_TRY(h, dev_realloc(h->draws, (size_t)n_pad));
+        HIP_TRY(h, dev_realloc(h->rec, (size_t)n_pad * 18));
+        h->cap = n_pad;
+    }
+    h->N = N; h->N_pad = n_pad; h->z3 = z3; h->rad = rad;
+    h->i_begin = 0; h->i_end = N; h->cur = 0; h->rec_valid = false; h->timing_valid = false;
+    if (N == 0) return SFM_OK;
+    std::vector<float4> pk((size_t)n_pad, make_float4(0.f, 0.f, 0.f, 0.f)), own((size_t)n_pad, make_float4(0.f, 0.f, 0.f, 0.f));
+    std::vector<float2> zv((size_t)n_pad, make_float2(0.f, 0.f));
+    std::vector<float> rr((size_t)n_pad, 0.f);
+    std::vector<uint8_t> cm((size_t)n_pad, 0);
+    for (int i = 0; i < N; ++i) {
+        pk[i] = make_float4(x[i], y[i], vx[i], vy[i]);
+        own[i] = make_float4(wx[i], wy[i], target_speed[i], radius ? radius[i] : 0.f);
+        if (z3) zv[i] = make_float2(z[i], vz[i]);
+        if (radius) rr[i] = radius[i];
+        if (crossing_mask) cm[i] = crossing_mask[i] ? 1 : 0;
+    }
+    for (int b = 0; b < 2; ++b) {
+        HIP_TRY(h, hipMemcpy(h->pk[b], pk.data(), sizeof(float4) * (size_t)n_pad, hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(h->zv[b], zv.data(), sizeof(float2) * (size_t)n_pad, hipMemcpyHostToDevice));
+    }
+    HIP_TRY(h, hipMemcpy(h->own, own.data(), sizeof(float4) * (size_t)n_pad, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->radius, rr.data(), sizeof(float) * (size_t)n_pad, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->crossing, cm.data(), (size_t)n_pad, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemset(h->draws, 0, sizeof(uint32_t) * (size_t)n_pad));
+    return SFM_OK;
+}
+
+int sfm_set_shard(SfmHandle* h, int i_begin, int i_end) {
+    if (!h) return SFM_ERR_INVALID;
+    if (i_begin < 0 || i_end < i_begin || i_end > h->N) return fail(h, SFM_ERR_INVALID, "shard out of range");
+    h->i_begin = i_begin;
+    h->i_end = i_end;
+    return SFM_OK;
+}
+
+int sfm_set_waypoint_stream(SfmHandle* h, uint32_t seed, float world_side, float arrive_threshold) {
+    if (!h) return SFM_ERR_INVALID;
+    h->seed = seed;
+    h->world_side = world_side;
+    h->arrive_thr = arrive_threshold;
+    return SFM_OK;
+}
+
+static int pick_ipw(const SfmHandle* h, int n_local) {
+    if (h->ipw_override == 1 || h->ipw_override == 2 || h->ipw_override == 4 || h->ipw_override == 8)
+        return h->ipw_override;
+    // keep >= 2 waves on each of the 1024 SIMDs when the shard allows it
+    if (n_local >= 8 * 2048) return 8;
+    if (n_local >= 4 * 2048) return 4;
+    if (n_local >= 2 * 2048) return 2;
+    return 1;
+}
+
+static void fill_args(SfmHandle* h, TickArgs& a, uint32_t flags) {
+    const SfmParams& p = h->prm;
+    memset(&a, 0, sizeof(a));
+    a.pk_cur = h->pk[h->cur];
+    a.pk_next = h->pk[h->cur ^ 1];
+    a.zv_cur = h->zv[h->cur];
+    a.zv_next = h->zv[h->cur ^ 1];
+    a.own = h->own;
+    a.radius = h->radius;
+    a.crossing = h->crossing;
+    a.draws = h->draws;
+    a.rec = (flags & SFM_TICK_RECORD_FORCES) ? h->rec : nullptr;
+    a.N = h->N; a.i_begin = h->i_begin; a.i_end = h->i_end;
+    a.flags = flags;
+    a.en_acc = p.enabled[SFM_FORCE_ACCELERATION];
+    a.en_ped = p.enabled[SFM_FORCE_PEDESTRIAN];
+    a.en_border = p.enabled[SFM_FORCE_BORDER];
+    a.en_static = p.enabled[SFM_FORCE_STATIC_OBSTACLE];
+    a.en_dynamic = p.enabled[SFM_FORCE_DYNAMIC_OBSTACLE];
+    a.ped = fold(p.pedestrian);
+    a.stat = fold(p.static_obstacle);
+    a.dyn = fold(p.dynamic_obstacle);
+    a.border_a = p.border_a;
+    a.border_nlb = (float)(-1.4426950408889634 / (double)p.border_b);
+    a.inv_tau = (float)(1.0 / (double)p.tau);
+    a.dt = p.step_length;
+    a.max_speed_factor = p.max_speed_factor;
+    a.seed = h->seed;
+    a.world_side = h->world_side;
+    a.arrive_thr2 = (float)((double)h->arrive_thr * (double)h->arrive_thr);
+    a.borders = Geo{h->borders.off, h->borders.pts, h->borders.ctr, h->borders.K};
+    a.statics = Geo{h->statics.off, h->statics.pts, h->statics.ctr, h->statics.K};
+    a.dynamics = Geo{h->dynamics.off, h->dynamics.pts, h->dynamics.ctr, h->dynamics.K};
+}
+
+static int run_ticks(SfmHandle* h, int ticks, uint32_t flags) {
+    int rc = bind(h);
+    if (rc) return rc;
+    if (ticks < 0) return fail(h, SFM_ERR_INVALID, "ticks < 0");
+    h->timing_valid = false;
+    if (h->N == 0 || ticks == 0) return SFM_OK;        // tick() early-out (pedestrian_simulation.py:60-61)
+    if (!h->pk[0]) return fail(h, SFM_ERR_STATE, "sfm_upload_state has not been called");
+    const int n_local = h->i_end - h->i_begin;
+    const int ipw = pick_ipw(h, n_local);
+    h->ipw_last = ipw;
+    snprintf(h->variant, sizeof(h->variant), "sfm_tick_kernel<%d,%s,%s>", ipw, h->z3 ? "true" : "false",
+             h->rad ? "true" : "false");
+    HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+    int launches = 0;
+    for (int t = 0; t < ticks; ++t) {
+        TickArgs a;
+        fill_args(h, a, flags);
+        if (n_local > 0) {
+            HIP_TRY(h, launch_tick(ipw, h->z3, h->rad, a, h->stream));
+            ++launches;
+        }
+        h->cur ^= 1;
+    }
+    HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
+    h->timed_ticks = ticks;
+    h->timed_launches = launches;
+    h->timing_valid = true;
+    h->rec_valid = (flags & SFM_TICK_RECORD_FORCES) != 0;
+    return SFM_OK;
+}
+
+int sfm_tick(SfmHandle* h, uint32_t flags) { return run_ticks(h, 1, flags); }
+
+int sfm_run(SfmHandle* h, int ticks, uint32_t flags) { return run_ticks(h, ticks, flags | SFM_TICK_INTEGRATE); }
+
+// ---- downloads ------------------------------------------------------------------------------------
+
+static int fetch_packed(SfmHandle* h, std::vector<float4>& pk, std::vector<float2>& zv, bool want_z) {
+    const int n = h->i_end - h->i_begin;
+    pk.resize((size_t)n);
+    HIP_TRY(h, hipMemcpyAsync(pk.data(), h->pk[h->cur] + h->i_begin, sizeof(float4) * (size_t)n,
+                              hipMemcpyDeviceToHost, h->stream));
+    if (want_z && h->z3) {
+        zv.resize((size_t)n);
+        HIP_TRY(h, hipMemcpyAsync(zv.data(), h->zv[h->cur] + h->i_begin, sizeof(float2) * (size_t)n,
+                                  hipMemcpyDeviceToHost, h->stream));
+    }
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SFM_OK;
+}
+
+int sfm_download_velocities(SfmHandle* h, float* vx, float* vy, float* vz) {
+    int rc = bind(h);
+    if (rc) return rc;
+    if (h->N == 0) return SFM_OK;
+    if (!vx || !vy) return fail(h, SFM_ERR_INVALID, "vx / vy is NULL");
+    std::vector<float4> pk;
+    std::vector<float2> zv;
+    rc = fetch_packed(h, pk, zv, vz != nullptr);
+    if (rc) return rc;
+    for (int i = h->i_begin; i < h->i_end; ++i) {
+        vx[i] = pk[i - h->i_begin].z;
+        vy[i] = pk[i - h->i_begin].w;
+        if (vz) vz[i] = h->z3 ? zv[i - h->i_begin].y : 0.f;
+    }
+    return SFM_OK;
+}
+
+int sfm_download_state(SfmHandle* h, float* x, float* y, float* z, float* vx, float* vy, float* vz, float* wx,
+                       float* wy) {
+    int rc = bind(h);
+    if (rc) return rc;
+    if (h->N == 0) return SFM_OK;
+    std::vector<float4> pk, own;
+    std::vector<float2> zv;
+    rc = fetch_packed(h, pk, zv, z || vz);
+    if (rc) return rc;
+    const int n = h->i_end - h->i_begin;
+    if (wx || wy) {
+        own.resize((size_t)n);
+        HIP_TRY(h, hipMemcpy(own.data(), h->own + h->i_begin, sizeof(float4) * (size_t)n, hipMemcpyDeviceToHost));
+    }
+    for (int i = h->i_begin; i < h->i_end; ++i) {
+        const int k = i - h->i_begin;
+        if (x) x[i] = pk[k].x;
+        if (y) y[i] = pk[k].y;
+        if (vx) vx[i] = pk[k].z;
+        if (vy) vy[i] = pk[k].w;
+        if (z) z[i] = h->z3 ? zv[k].x : 0.f;
+        if (vz) vz[i] = h->z3 ? zv[k].y : 0.f;
+        if (wx) wx[i] = own[k].x;
+        if (wy) wy[i] = own[k].y;
+    }
+    return SFM_OK;
+}
+
+int sfm_download_forces(SfmHandle* h, int which, float* fx, float* fy, float* fz) {
+    int rc = bind(h);
+    if (rc) return rc;
+    if (which < 0 || which > SFM_FORCE_TOTAL) return fail(h, SFM_ERR_INVALID, "unknown force index");
+    if (h->N == 0) return SFM_OK;
+    if (!h->rec_valid) return fail(h, SFM_ERR_STATE, "last tick did not run with SFM_TICK_RECORD_FORCES");
+    if (!fx || !fy) return fail(h, SFM_ERR_INVALID, "fx / fy is NULL");
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const size_t n = (size_t)h->N;
+    const int cnt = h->i_end - h->i_begin;
+    float* dst[3] = {fx, fy, fz};
+    for (int c = 0; c < 3; ++c) {
+        if (!dst[c]) continue;
+        HIP_TRY(h, hipMemcpy(dst[c] + h->i_begin, h->rec + ((size_t)which * 3 + c) * n + h->i_begin,
+                             sizeof(float) * (size_t)cnt, hipMemcpyDeviceToHost));
+    }
+    return SFM_OK;
+}
+
+int sfm_get_arrived(SfmHandle* h, float threshold, uint8_t* mask) {
+    int rc = bind(h);
+    if (rc) return rc;
+    if (h->N == 0) return SFM_OK;
+    if (!mask) return fail(h, SFM_ERR_INVALID, "mask is NULL");
+    const float thr2 = (float)((double)threshold * (double)threshold);
+    HIP_TRY(h, launch_arrived(h->pk[h->cur], h->own, h->N, thr2, h->arrived, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(mask, h->arrived, (size_t)h->N, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SFM_OK;
+}
+
+int sfm_download_draw_counts(SfmHandle* h, uint32_t* counts) {
+    int rc = bind(h);
+    if (rc) return rc;
+    if (h->N == 0) return SFM_OK;
+    if (!counts) return fail(h, SFM_ERR_INVALID, "counts is NULL");
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpy(counts + h->i_begin, h->draws + h->i_begin, sizeof(uint32_t) * (size_t)(h->i_end - h->i_begin),
+                         hipMemcpyDeviceToHost));
+    return SFM_OK;
+}
+
+void* sfm_packed_state_ptr(SfmHandle* h, int* n_pad) {
+    if (!h) return nullptr;
+    if (n_pad) *n_pad = h->N_pad;
+    return h->pk[h->cur];
+}
+
+void* sfm_packed_z_ptr(SfmHandle* h) {
+    if (!h || !h->z3) return nullptr;
+    return h->zv[h->cur];
+}
+
+const char* sfm_last_error(const SfmHandle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int sfm_get_timing(SfmHandle* h, float* elapsed_ms, int* ticks, int* launches) {
+    int rc = bind(h);
+    if (rc) return rc;
+    if (!h->timing_valid) return fail(h, SFM_ERR_STATE, "no timed run yet");
+    HIP_TRY(h, hipEventSynchronize(h->ev1));
+    float ms = 0.f;
+    HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    if (elapsed_ms) *elapsed_ms = ms;
+    if (ticks) *ticks = h->timed_ticks;
+    if (launches) *launches = h->timed_launches;
+    return SFM_OK;
+}
+
+const char* sfm_kernel_variant(const SfmHandle* h) { return h ? h->variant : "none"; }
+
+}  // extern "C"

@@ -1,0 +1,60 @@
+// sfm_device.h -- device-side data layout and folded constants shared by the kernels and the C ABI.
+// gfx950 (MI355X) only.  See DESIGN.md for the layout rationale.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sfm {
+
+constexpr int WAVE = 64;
+constexpr int BLOCK = 256;            // 4 waves per workgroup
+constexpr int WAVES_PER_BLOCK = BLOCK / WAVE;
+constexpr int TILE_J = BLOCK;         // j-records staged per LDS tile (one float4 per thread)
+constexpr float TINY = 1e-30f;        // added under every rsq: zero vectors normalise to zero without a guard op
+constexpr float COINCIDENT_RINV = 1e14f;  // rsq(d2) above this <=> a coincident (or < 1e-14 m) valid pair
+
+// Moussaid interaction constants, folded on the host in double and rounded once
+// (forces.py:85-109 for pedestrians, :241-264 for obstacles).
+struct IxConst {
+    float lam;    // lambda                                   D = lam*(v_i - v_j) + e
+    float eg;     // epsilon*gamma                            theta = angle - eg*|D|          (B = gamma*|D|)
+    float c1;     // -log2(e)/gamma                           -d/B * log2(e) = d * (1/|D|) * c1
+    float k1;     // -(n_prime*gamma)^2 * log2(e)             -(n' B theta)^2 * log2(e) = (|D| theta)^2 * k1
+    float k2;     // -(n*gamma)^2 * log2(e)
+    float negA;   // -A
+    float thr2;   // perception_threshold^2 (obstacles only)
+    float pad;
+};
+
+struct Geo {                  // CSR polylines / rings
+    const int* off;           // [K+1]
+    const float2* pts;        // [P] {x, y}
+    const float4* ctr;        // [K] borders: {cx, cy, section_length^2, 0}; obstacles: {cx, cy, vx, vy}
+    int K;
+};
+
+struct TickArgs {
+    // packed j-operand state, N_pad records (padding rows are never selected)
+    const float4* pk_cur;     // {x, y, vx, vy}
+    float4* pk_next;
+    const float2* zv_cur;     // {z, vz}, 3-D variant only
+    float2* zv_next;
+    float4* own;              // {wx, wy, target_speed, radius}
+    const float* radius;      // [N_pad] radius stream for the j side (use_ped_radius only)
+    const uint8_t* crossing;  // border-force mask
+    uint32_t* draws;          // waypoint draw counters
+    float* rec;               // optional per-force record, layout [6][3][N]
+    int N, i_begin, i_end;
+    uint32_t flags;
+    // parameters
+    int en_acc, en_ped, en_border, en_static, en_dynamic;
+    IxConst ped, stat, dyn;
+    float border_a, border_nlb;   // a, -log2(e)/b
+    float inv_tau, dt, max_speed_factor;
+    // waypoint stream
+    uint32_t seed;
+    float world_side, arrive_thr2;
+    Geo borders, statics, dynamics;
+};
+
+}  // namespace sfm

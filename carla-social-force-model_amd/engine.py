@@ -1,0 +1,253 @@
+"""NumPy-level wrapper of one libsfm_hip handle (one GPU).
+
+Converts the reference's host formats -- float64 (N,3) columns of the PedState record, lists of (P_k,2)
+polylines, ``(center, ring)`` obstacle tuples -- to the fp32 SoA / CSR arrays of the C ABI and back.
+Used by the drop-in facade (pedestrian_simulation.py, forces.py) and by the device-resident stepper.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import FORCE_NAMES, FORCE_TOTAL, SfmLibraryError, f32, fptr, iptr, u8ptr
+
+
+def interaction_from_table(tbl):
+    """Same keys and code-side defaults as the reference getters (forces.py:66-72, :196-206)."""
+    return _lib.SfmInteraction(tbl.get("lambda", 2.0), tbl.get("A", 4.5), tbl.get("gamma", 0.35),
+                               tbl.get("n", 2.0), tbl.get("n_prime", 3.0), tbl.get("epsilon", 0.005),
+                               tbl.get("perception_threshold", 20))
+
+
+def params_from_config(sfm_config, step_length, honour_file_keys=False):
+    """Build the C parameter block from an sfm_config dict, reading it exactly as the reference does.
+
+    Bug-compatible by default: tau is looked up under ``[goal_force]``
+    (forces.py:44) and the speed factor under ``max_speed_factor`` (pedestrian_state.py:15), so the stock
+    file's ``[acceleration_force] tau`` and ``max_speed_multiplier`` are ignored and 0.5 / 1.3 apply.
+    ``honour_file_keys=True`` is the documented deviation that reads those two file keys instead.
+    The parameter table of an enabled force is mandatory (KeyError, forces.py:66,134,197-199)."""
+    act = sfm_config["forces"]
+    p = _lib.SfmParamsC()
+    p.use_ped_radius = int(bool(sfm_config.get("use_ped_radius", False)))
+    p.max_speed_factor = sfm_config.get("max_speed_factor", 1.3)
+    p.tau = sfm_config.get("goal_force", {}).get("tau", 0.5)
+    if honour_file_keys:
+        p.max_speed_factor = sfm_config.get("max_speed_multiplier", p.max_speed_factor)
+        p.tau = sfm_config.get("acceleration_force", {}).get("tau", p.tau)
+    p.step_length = float(step_length)
+    for k, name in enumerate(FORCE_NAMES):
+        p.enabled[k] = int(bool(act.get(name, False)))
+    for bad in ("ped_repulsive_force", "space_repulsive_force"):
+        if act.get(bad, False):   # pedestrian_simulation.py:49-53 reference classes that do not exist
+            raise AttributeError(f"module 'forces' has no attribute for '{bad}'")
+    dflt = _lib.SfmInteraction(2.0, 4.5, 0.35, 2.0, 3.0, 0.005, 20.0)
+    p.pedestrian = interaction_from_table(sfm_config["pedestrian_force"]) if p.enabled[1] else dflt
+    if p.enabled[2]:
+        tbl = sfm_config["border_force"]
+        p.border_a, p.border_b = tbl.get("a", 3.0), tbl.get("b", 0.1)
+    else:
+        p.border_a, p.border_b = 3.0, 0.1
+    p.static_obstacle = interaction_from_table(sfm_config["static_obstacle_force"]) if p.enabled[3] else dflt
+    p.dynamic_obstacle = interaction_from_table(sfm_config["dynamic_obstacle_force"]) if p.enabled[4] else dflt
+    return p
+
+
+def _csr(polys):
+    off = np.zeros(len(polys) + 1, dtype=np.int32)
+    for k, pl in enumerate(polys):
+        off[k + 1] = off[k] + len(pl)
+    if len(polys) and off[-1] > 0:
+        pts = np.concatenate([np.asarray(pl, dtype=np.float64).reshape(-1, 2) for pl in polys], axis=0)
+    else:
+        pts = np.zeros((0, 2))
+    return off, f32(pts[:, 0]), f32(pts[:, 1])
+
+
+class SfmEngine:
+    """One libsfm_hip handle.  Raises SfmLibraryError on any failure; never falls back to the CPU."""
+
+    def __init__(self, sfm_config, step_length, device=0, honour_file_keys=False, stream=None):
+        self._lib = _lib.load()
+        self._h = C.c_void_p()
+        self.params = params_from_config(sfm_config, step_length, honour_file_keys)
+        rc = self._lib.sfm_create(C.byref(self.params), int(device), C.byref(self._h))
+        if rc != 0:
+            msg = self._lib.sfm_last_error(None)
+            self._h = C.c_void_p()
+            raise SfmLibraryError(f"sfm_create failed ({rc}): {msg.decode() if msg else '?'}")
+        self.n = 0
+        self.shard = (0, 0)
+        self.planar = True
+        if stream is not None:
+            self.set_stream(stream)
+
+    # ---- plumbing ---------------------------------------------------------------------------------
+    def _check(self, rc, what):
+        if rc != 0:
+            msg = self._lib.sfm_last_error(self._h)
+            raise SfmLibraryError(f"{what} failed ({rc}): {msg.decode() if msg else '?'}")
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.sfm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream_ptr):
+        self._check(self._lib.sfm_set_stream(self._h, C.c_void_p(int(stream_ptr))), "sfm_set_stream")
+
+    def set_params(self, sfm_config, step_length, honour_file_keys=False):
+        self.params = params_from_config(sfm_config, step_length, honour_file_keys)
+        self._check(self._lib.sfm_set_params(self._h, C.byref(self.params)), "sfm_set_params")
+
+    # ---- geometry ---------------------------------------------------------------------------------
+    def set_borders(self, borders, centers, lengths):
+        """borders: list of (P_k,2); centers (K,2); lengths (K,)  (forces.py:127-132)."""
+        K = len(borders)
+        if K == 0:
+            self._check(self._lib.sfm_set_borders(self._h, 0, None, None, None, None, None, None), "sfm_set_borders")
+            return
+        off, px, py = _csr(borders)
+        c = np.asarray(centers, dtype=np.float64).reshape(K, 2)
+        cx, cy, ln = f32(c[:, 0]), f32(c[:, 1]), f32(np.asarray(lengths, dtype=np.float64).reshape(K))
+        self._check(self._lib.sfm_set_borders(self._h, K, iptr(off), fptr(px), fptr(py), fptr(cx), fptr(cy), fptr(ln)),
+                    "sfm_set_borders")
+
+    def _obstacles(self, obstacles):
+        cs = np.array([np.asarray(c, dtype=np.float64)[:2] for c, _ in obstacles], dtype=np.float64).reshape(-1, 2)
+        off, px, py = _csr([r for _, r in obstacles])
+        return off, px, py, f32(cs[:, 0]), f32(cs[:, 1])
+
+    def set_static_obstacles(self, obstacles):
+        """obstacles: list of (center(2), ring(P,2))  (forces.py:285-288)."""
+        if obstacles is None or len(obstacles) == 0:
+            self._check(self._lib.sfm_set_static_obstacles(self._h, 0, None, None, None, None, None),
+                        "sfm_set_static_obstacles")
+            return
+        off, px, py, cx, cy = self._obstacles(obstacles)
+        self._check(self._lib.sfm_set_static_obstacles(self._h, len(obstacles), iptr(off), fptr(px), fptr(py),
+                                                       fptr(cx), fptr(cy)), "sfm_set_static_obstacles")
+
+    def set_dynamic_obstacles(self, obstacles, velocities=None):
+        """obstacles as above + velocities (M,2) or None (zeros, forces.py:212-213)."""
+        if obstacles is None or len(obstacles) == 0:
+            self._check(self._lib.sfm_set_dynamic_obstacles(self._h, 0, None, None, None, None, None, None, None),
+                        "sfm_set_dynamic_obstacles")
+            return
+        off, px, py, cx, cy = self._obstacles(obstacles)
+        M = len(obstacles)
+        if velocities is None:
+            vx = vy = None
+        else:
+            v = np.asarray(velocities, dtype=np.float64).reshape(M, 2)
+            vx, vy = f32(v[:, 0]), f32(v[:, 1])
+        self._check(self._lib.sfm_set_dynamic_obstacles(self._h, M, iptr(off), fptr(px), fptr(py), fptr(cx), fptr(cy),
+                                                        fptr(vx), fptr(vy)), "sfm_set_dynamic_obstacles")
+
+    # ---- state ------------------------------------------------------------------------------------
+    def upload_state(self, loc, vel, waypoint, target_speed, radius=None, crossing=None, planar=None):
+        """loc, vel, waypoint: (N,3) float; target_speed, radius: (N,); crossing: (N,) bool.
+        ``planar`` None = auto: the 2-D kernel is used iff all z are equal and all v_z are 0 (then the
+        3-component formulas of forces.py:74-117 / stateutils.py:18-23 reduce to it exactly)."""
+        loc = np.asarray(loc, dtype=np.float64).reshape(-1, 3)
+        vel = np.asarray(vel, dtype=np.float64).reshape(-1, 3)
+        wp = np.asarray(waypoint, dtype=np.float64).reshape(-1, 3)
+        n = loc.shape[0]
+        if planar is None:
+            planar = n == 0 or (bool(np.all(loc[:, 2] == loc[0, 2])) and not bool(np.any(vel[:, 2] != 0.0)))
+        self.planar = planar
+        self._z0 = float(loc[0, 2]) if n else 0.0
+        x, y, vx, vy = f32(loc[:, 0]), f32(loc[:, 1]), f32(vel[:, 0]), f32(vel[:, 1])
+        z, vz = (None, None) if planar else (f32(loc[:, 2]), f32(vel[:, 2]))
+        wx, wy = f32(wp[:, 0]), f32(wp[:, 1])
+        ts = f32(target_speed)
+        rr = None if radius is None else f32(radius)
+        cm = None if crossing is None else np.ascontiguousarray(crossing, dtype=np.uint8)
+        self._check(self._lib.sfm_upload_state(self._h, n, fptr(x), fptr(y), fptr(z), fptr(vx), fptr(vy), fptr(vz),
+                                               fptr(wx), fptr(wy), fptr(ts), fptr(rr), u8ptr(cm)), "sfm_upload_state")
+        self.n = n
+        self.shard = (0, n)
+
+    def set_shard(self, i_begin, i_end):
+        self._check(self._lib.sfm_set_shard(self._h, int(i_begin), int(i_end)), "sfm_set_shard")
+        self.shard = (int(i_begin), int(i_end))
+
+    def set_waypoint_stream(self, seed, world_side, arrive_threshold=2.0):
+        self._check(self._lib.sfm_set_waypoint_stream(self._h, int(seed) & 0xFFFFFFFF, float(world_side),
+                                                      float(arrive_threshold)), "sfm_set_waypoint_stream")
+
+    # ---- stepping ---------------------------------------------------------------------------------
+    @staticmethod
+    def _flags(integrate, redraw, record):
+        return ((_lib.TICK_INTEGRATE if integrate else 0) | (_lib.TICK_REDRAW_WAYPOINTS if redraw else 0)
+                | (_lib.TICK_RECORD_FORCES if record else 0))
+
+    def tick(self, integrate=False, redraw=False, record=False):
+        self._check(self._lib.sfm_tick(self._h, self._flags(integrate, redraw, record)), "sfm_tick")
+
+    def run(self, ticks, redraw=False, record=False):
+        self._check(self._lib.sfm_run(self._h, int(ticks), self._flags(True, redraw, record)), "sfm_run")
+
+    # ---- results ----------------------------------------------------------------------------------
+    def velocities(self):
+        """(N,3) float64; rows outside this handle's shard are NaN."""
+        n = self.n
+        vx, vy, vz = (np.full(n, np.nan, np.float32) for _ in range(3))
+        self._check(self._lib.sfm_download_velocities(self._h, fptr(vx), fptr(vy), fptr(vz)), "sfm_download_velocities")
+        return np.stack([vx, vy, vz], axis=1).astype(np.float64)
+
+    def state(self):
+        n = self.n
+        a = {k: np.full(n, np.nan, np.float32) for k in ("x", "y", "z", "vx", "vy", "vz", "wx", "wy")}
+        self._check(self._lib.sfm_download_state(self._h, *(fptr(a[k]) for k in ("x", "y", "z", "vx", "vy", "vz", "wx", "wy"))),
+                    "sfm_download_state")
+        if self.planar:
+            a["z"][self.shard[0]:self.shard[1]] = np.float32(self._z0)
+        loc = np.stack([a["x"], a["y"], a["z"]], axis=1).astype(np.float64)
+        vel = np.stack([a["vx"], a["vy"], a["vz"]], axis=1).astype(np.float64)
+        wp = np.stack([a["wx"], a["wy"]], axis=1).astype(np.float64)
+        return loc, vel, wp
+
+    def forces(self, which):
+        """(N,3) float64 of one force (name or index; 'total' = 5) from the last recorded tick."""
+        if isinstance(which, str):
+            which = FORCE_TOTAL if which == "total" else FORCE_NAMES.index(which)
+        n = self.n
+        fx, fy, fz = (np.full(n, np.nan, np.float32) for _ in range(3))
+        self._check(self._lib.sfm_download_forces(self._h, int(which), fptr(fx), fptr(fy), fptr(fz)), "sfm_download_forces")
+        return np.stack([fx, fy, fz], axis=1).astype(np.float64)
+
+    def arrived(self, threshold):
+        m = np.zeros(self.n, dtype=np.uint8)
+        self._check(self._lib.sfm_get_arrived(self._h, float(threshold), u8ptr(m)), "sfm_get_arrived")
+        return m.astype(bool)
+
+    def draw_counts(self):
+        c = np.zeros(self.n, dtype=np.uint32)
+        self._check(self._lib.sfm_download_draw_counts(self._h, c.ctypes.data_as(_lib._U32)), "sfm_download_draw_counts")
+        return c
+
+    def packed_state_ptr(self):
+        npad = C.c_int(0)
+        p = self._lib.sfm_packed_state_ptr(self._h, C.byref(npad))
+        return p, npad.value
+
+    def packed_z_ptr(self):
+        return self._lib.sfm_packed_z_ptr(self._h)
+
+    def timing(self):
+        """(elapsed_ms, ticks, launches) of the last tick()/run(), HIP events on the handle's stream."""
+        ms, t, l = C.c_float(0), C.c_int(0), C.c_int(0)
+        self._check(self._lib.sfm_get_timing(self._h, C.byref(ms), C.byref(t), C.byref(l)), "sfm_get_timing")
+        return ms.value, t.value, l.value
+
+    def kernel_variant(self):
+        return self._lib.sfm_kernel_variant(self._h).decode()

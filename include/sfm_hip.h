@@ -1,0 +1,164 @@
+/*
+ * sfm_hip.h -- C ABI of libsfm_hip.so: the MI355X (gfx950) Social-Force-Model stepper.
+ *
+ * Drop-in boundary for ONE hot path of felixlutz/carla-social-force-model: forces.py + stateutils.py +
+ * the numeric half of pedestrian_simulation.py.  The reference is pure Python and has no FFI layer of
+ * its own, so each entry point below names the reference interface it replaces (file:line, relative to
+ * the upstream repository); INTEGRATION.md shows the ctypes binding a maintainer would add.
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 on success or a negative
+ * SfmStatus; sfm_last_error() gives the message of the last failure on a handle (or of the last failed
+ * sfm_create when called with NULL).  The caller owns every host buffer; the library owns all device
+ * memory behind the opaque handle.  A handle drives ONE GPU and is not thread-safe; distinct handles are
+ * independent.  Arithmetic is fp32 on the device; host arrays are fp32 SoA (one array per component).
+ * All work is issued on the handle's stream (sfm_set_stream; default: the null stream); the download /
+ * query calls synchronise that stream.
+ */
+#ifndef SFM_HIP_H
+#define SFM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SFM_ABI_VERSION 1
+
+typedef struct SfmHandle SfmHandle;
+
+typedef enum SfmStatus {
+    SFM_OK = 0,
+    SFM_ERR_INVALID = -1,   /* bad argument (NULL pointer, negative size, inconsistent CSR offsets ...) */
+    SFM_ERR_HIP = -2,       /* a HIP runtime call failed; message in sfm_last_error */
+    SFM_ERR_STATE = -3,     /* call order: e.g. sfm_tick before sfm_upload_state */
+    SFM_ERR_NO_DEVICE = -4  /* no usable gfx950 device */
+} SfmStatus;
+
+/* Index of each force: the dict order of PedestrianSimulation.init_forces (pedestrian_simulation.py:37-48),
+ * which is also the summation order of tick() (:81). */
+enum { SFM_FORCE_ACCELERATION = 0, SFM_FORCE_PEDESTRIAN = 1, SFM_FORCE_BORDER = 2,
+       SFM_FORCE_STATIC_OBSTACLE = 3, SFM_FORCE_DYNAMIC_OBSTACLE = 4, SFM_NUM_FORCES = 5,
+       SFM_FORCE_TOTAL = 5 };
+
+/* One Moussaid parameter table: [pedestrian_force] (forces.py:66-72), [static_obstacle_force] /
+ * [dynamic_obstacle_force] (forces.py:196-206). perception_threshold is unused for pedestrians. */
+typedef struct SfmInteraction {
+    float lambda, A, gamma, n, n_prime, epsilon, perception_threshold;
+} SfmInteraction;
+
+/* Mirrors config/sfm_config.toml as the reference *reads* it. */
+typedef struct SfmParams {
+    int32_t use_ped_radius;            /* forces.py:18 */
+    float   max_speed_factor;          /* pedestrian_state.py:15 (1.3) */
+    float   tau;                       /* forces.py:44 (0.5) */
+    float   step_length;               /* run_simulation.py:168 (0.05 s) */
+    int32_t enabled[SFM_NUM_FORCES];   /* [forces] switches, pedestrian_simulation.py:33-48 */
+    SfmInteraction pedestrian;
+    float   border_a, border_b;        /* forces.py:134-136 */
+    SfmInteraction static_obstacle;
+    SfmInteraction dynamic_obstacle;
+} SfmParams;
+
+/* sfm_tick / sfm_run flags */
+enum {
+    SFM_TICK_INTEGRATE = 1u,        /* also x <- x + dt*v' : the CARLA-free stand-in for the simulator that moves
+                                       the walkers between ticks (run_simulation.py:77-87, carla_simulation.py:126-129) */
+    SFM_TICK_REDRAW_WAYPOINTS = 2u, /* on arrival (pedestrian_simulation.py:92-95) draw the next waypoint from the
+                                       counter-based stream set by sfm_set_waypoint_stream (run_simulation.py:118-126) */
+    SFM_TICK_RECORD_FORCES = 4u     /* keep the per-force arrays for sfm_download_forces (Force.get_force, forces.py:28-32) */
+};
+
+/* ---- lifetime ------------------------------------------------------------------------------------ */
+
+/* PedestrianSimulation.__init__ + init_forces (pedestrian_simulation.py:11-55): capture the parameters,
+ * create the device context on `device_id`. */
+int sfm_create(const SfmParams* params, int device_id, SfmHandle** out);
+int sfm_destroy(SfmHandle* h);                                   /* PedestrianSimulation.close (:85) */
+int sfm_set_params(SfmHandle* h, const SfmParams* params);       /* Force.__init__ captures (forces.py:14-18) */
+int sfm_set_stream(SfmHandle* h, void* hip_stream);              /* hipStream_t; NULL = null stream */
+
+/* ---- geometry (CSR: offsets[K+1], points SoA) ------------------------------------------------------ */
+
+/* BorderForce.__init__ (forces.py:127-136): K polylines, centre and full section_length as cull radius
+ * (forces.py:149-150; obstacles.py:129-131,352-355). K = 0 clears. */
+int sfm_set_borders(SfmHandle* h, int K, const int32_t* offsets, const float* px, const float* py,
+                    const float* cx, const float* cy, const float* cull_len);
+/* ObstacleForce.update_obstacles for the static force (forces.py:285-288; pedestrian_simulation.py:45-46). */
+int sfm_set_static_obstacles(SfmHandle* h, int M, const int32_t* offsets, const float* px, const float* py,
+                             const float* cx, const float* cy);
+/* update_obstacles + update_obstacle_velocities for the dynamic force, once per tick
+ * (pedestrian_simulation.py:108-115; forces.py:285-291). */
+int sfm_set_dynamic_obstacles(SfmHandle* h, int M, const int32_t* offsets, const float* px, const float* py,
+                              const float* cx, const float* cy, const float* vx, const float* vy);
+
+/* ---- state ----------------------------------------------------------------------------------------- */
+
+/* The numeric columns of PedState.state (pedestrian_state.py:17-19) as fp32 SoA: loc, vel, next_waypoint,
+ * target_speed (already refreshed from the modes, :94-95), radius, and the border-force mask
+ * mode in {CROSSING_ROAD, ROAD_TO_SIDEWALK} (forces.py:176-177).
+ * z / vz may both be NULL (planar crowd: the 2-D kernel variant is used); radius may be NULL when
+ * use_ped_radius is 0; crossing_mask may be NULL (all zero).  N = 0 is allowed (tick is a no-op, :60-61). */
+int sfm_upload_state(SfmHandle* h, int N,
+                     const float* x, const float* y, const float* z,
+                     const float* vx, const float* vy, const float* vz,
+                     const float* wx, const float* wy,
+                     const float* target_speed, const float* radius, const uint8_t* crossing_mask);
+
+/* Rows [i_begin, i_end) this handle computes and integrates (pedestrian index sharding across GPUs,
+ * SURVEY.md section 8e).  Default after sfm_upload_state: [0, N).  All N pedestrians stay resident as the
+ * j-operand set; after each tick the caller all-gathers the packed state (below) across ranks. */
+int sfm_set_shard(SfmHandle* h, int i_begin, int i_end);
+
+/* Counter-based waypoint stream of the synthetic scenarios: on arrival within `arrive_threshold`
+ * (run_simulation.py:39) pedestrian i draws waypoint number k from hash(seed, i, k) in [0, world_side)^2. */
+int sfm_set_waypoint_stream(SfmHandle* h, uint32_t seed, float world_side, float arrive_threshold);
+
+/* ---- stepping -------------------------------------------------------------------------------------- */
+
+/* One fused tick: F = sum of the enabled forces (pedestrian_simulation.py:81), v' = cap(v + dt*F,
+ * max_speed_factor*target_speed) (:117-124; stateutils.py:18-23) written in place of v. */
+int sfm_tick(SfmHandle* h, uint32_t flags);
+/* `ticks` ticks back to back without host intervention (device-resident loop for benchmarks and the
+ * CARLA-free harness); flags as above, SFM_TICK_INTEGRATE is implied. */
+int sfm_run(SfmHandle* h, int ticks, uint32_t flags);
+
+/* ---- results --------------------------------------------------------------------------------------- */
+
+/* get_new_velocities (pedestrian_simulation.py:126-127): v' of this handle's shard rows, written at
+ * [i_begin, i_end) of the caller's length-N arrays.  vz may be NULL. */
+int sfm_download_velocities(SfmHandle* h, float* vx, float* vy, float* vz);
+/* Whole numeric state of the shard rows (any pointer may be NULL to skip that column). */
+int sfm_download_state(SfmHandle* h, float* x, float* y, float* z, float* vx, float* vy, float* vz,
+                       float* wx, float* wy);
+/* Force.get_force (forces.py:28-32) of force `which` (SFM_FORCE_*, or SFM_FORCE_TOTAL) for the shard rows,
+ * from the last tick run with SFM_TICK_RECORD_FORCES.  fz may be NULL. */
+int sfm_download_forces(SfmHandle* h, int which, float* fx, float* fy, float* fz);
+/* get_arrived_peds (pedestrian_simulation.py:88-97): mask[i] = |wp_xy - x_xy| < threshold, current state. */
+int sfm_get_arrived(SfmHandle* h, float threshold, uint8_t* mask);
+/* Number of waypoint draws per pedestrian so far (shard rows). */
+int sfm_download_draw_counts(SfmHandle* h, uint32_t* counts);
+
+/* ---- multi-GPU plumbing ---------------------------------------------------------------------------- */
+
+/* Device pointer to the packed j-operand state the NEXT tick will read: N_pad records of 4 floats
+ * {x, y, vx, vy}.  After a tick the shard rows are fresh; the caller all-gathers the other rows into
+ * this buffer in place (one RCCL all-gather per tick).  *n_pad receives the padded record count. */
+void* sfm_packed_state_ptr(SfmHandle* h, int* n_pad);
+/* Same for the {z, vz} records (2 floats) of the 3-D variant; NULL when the crowd is planar. */
+void* sfm_packed_z_ptr(SfmHandle* h);
+
+/* ---- diagnostics ----------------------------------------------------------------------------------- */
+
+const char* sfm_last_error(const SfmHandle* h);
+/* HIP-event time of the last sfm_tick / sfm_run on its stream: total ms, ticks it covered and kernel
+ * launches it issued. */
+int sfm_get_timing(SfmHandle* h, float* elapsed_ms, int* ticks, int* launches);
+/* Name of the pair kernel variant the last tick used (for profiles), static storage. */
+const char* sfm_kernel_variant(const SfmHandle* h);
+int sfm_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SFM_HIP_H */

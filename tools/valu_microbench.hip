@@ -1,0 +1,64 @@
+// Measures per-SIMD issue rates of the VALU ops the pair body is made of (gfx950).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+typedef float float2v __attribute__((ext_vector_type(2)));
+template <int OP>
+__global__ void k(float* out, int iters, float seed) {
+    float a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    float2v p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7}, p4 = {a1, a3}, p5 = {a0, a2}, p6 = {a5, a7}, p7 = {a4, a6};
+    const float c = 1.0001f, d = 0.5f;
+    const float2v c2 = {c, c}, d2 = {d, d};
+    for (int i = 0; i < iters; ++i) {
+        if (OP == 0) {  // v_fma_f32 x8
+            a0 = fmaf(a0, c, d); a1 = fmaf(a1, c, d); a2 = fmaf(a2, c, d); a3 = fmaf(a3, c, d);
+            a4 = fmaf(a4, c, d); a5 = fmaf(a5, c, d); a6 = fmaf(a6, c, d); a7 = fmaf(a7, c, d);
+        } else if (OP == 1) {  // v_pk_fma_f32 x8
+            p0 = __builtin_elementwise_fma(p0, c2, d2); p1 = __builtin_elementwise_fma(p1, c2, d2);
+            p2 = __builtin_elementwise_fma(p2, c2, d2); p3 = __builtin_elementwise_fma(p3, c2, d2);
+            p4 = __builtin_elementwise_fma(p4, c2, d2); p5 = __builtin_elementwise_fma(p5, c2, d2);
+            p6 = __builtin_elementwise_fma(p6, c2, d2); p7 = __builtin_elementwise_fma(p7, c2, d2);
+        } else if (OP == 2) {  // v_exp_f32 x8
+            a0 = __builtin_amdgcn_exp2f(a0); a1 = __builtin_amdgcn_exp2f(a1); a2 = __builtin_amdgcn_exp2f(a2); a3 = __builtin_amdgcn_exp2f(a3);
+            a4 = __builtin_amdgcn_exp2f(a4); a5 = __builtin_amdgcn_exp2f(a5); a6 = __builtin_amdgcn_exp2f(a6); a7 = __builtin_amdgcn_exp2f(a7);
+        } else if (OP == 3) {  // v_rsq_f32 x8
+            a0 = __builtin_amdgcn_rsqf(a0); a1 = __builtin_amdgcn_rsqf(a1); a2 = __builtin_amdgcn_rsqf(a2); a3 = __builtin_amdgcn_rsqf(a3);
+            a4 = __builtin_amdgcn_rsqf(a4); a5 = __builtin_amdgcn_rsqf(a5); a6 = __builtin_amdgcn_rsqf(a6); a7 = __builtin_amdgcn_rsqf(a7);
+        } else if (OP == 4) {  // v_pk_mul_f32 x8
+            p0 = p0 * c2; p1 = p1 * c2; p2 = p2 * c2; p3 = p3 * c2; p4 = p4 * c2; p5 = p5 * c2; p6 = p6 * c2; p7 = p7 * c2;
+        } else if (OP == 5) {  // v_cmp + v_cndmask (select) x8
+            a0 = a0 > d ? a1 : a0; a1 = a1 > d ? a2 : a1; a2 = a2 > d ? a3 : a2; a3 = a3 > d ? a4 : a3;
+            a4 = a4 > d ? a5 : a4; a5 = a5 > d ? a6 : a5; a6 = a6 > d ? a7 : a6; a7 = a7 > d ? a0 : a7;
+        } else if (OP == 6) {  // mixed: 4 fma + 4 exp interleaved
+            a0 = fmaf(a0, c, d); a1 = __builtin_amdgcn_exp2f(a1); a2 = fmaf(a2, c, d); a3 = __builtin_amdgcn_exp2f(a3);
+            a4 = fmaf(a4, c, d); a5 = __builtin_amdgcn_exp2f(a5); a6 = fmaf(a6, c, d); a7 = __builtin_amdgcn_exp2f(a7);
+        }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y + p4.x + p4.y + p5.x + p5.y + p6.x + p6.y + p7.x + p7.y;
+}
+template <int OP>
+int run(const char* name, int waves_per_simd, float lanes_per_inst) {
+    const int blocks = 256 * waves_per_simd;  // 256 threads = 4 waves -> one wave per SIMD per block per CU
+    float* out; CHECK(hipMalloc(&out, sizeof(float) * blocks * 256));
+    const int iters = 20000;
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, out, 100, 0.001f);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0));
+    hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, out, iters, 0.001f);
+    CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+    const double insts_per_simd = (double)iters * 8 * waves_per_simd;   // wave-instructions issued on one SIMD
+    const double cyc = ms * 1e-3 * 2.4e9;
+    printf("%-14s waves/SIMD=%d  %.3f ms  %.2f cycles(@2.4GHz)/wave-inst  -> %.1f lane-ops/clk/SIMD\n", name, waves_per_simd, ms,
+           cyc / insts_per_simd, 64.0 * lanes_per_inst * insts_per_simd / cyc);
+    CHECK(hipFree(out));
+    return 0;
+}
+int main() {
+    for (int w : {1, 2, 4, 8}) {
+        run<0>("v_fma_f32", w, 1); run<1>("v_pk_fma_f32", w, 2); run<4>("v_pk_mul_f32", w, 2); run<2>("v_exp_f32", w, 1);
+        run<3>("v_rsq_f32", w, 1); run<5>("cmp+cndmask", w, 1); run<6>("fma+exp mix", w, 1);
+    }
+    return 0;
+}
