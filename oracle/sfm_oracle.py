@@ -27,6 +27,7 @@ from dataclasses import dataclass, field
 import numpy as np
 
 TWO_PI = 2.0 * np.pi
+FP32_ANGLE_RESOLUTION = 2.0 ** -22   # rad; see moussaid_term
 
 # PedMode values that switch the border force off (ped_mode_manager.py:4-9, forces.py:176-177)
 MODE_IDLE, MODE_WALKING_SIDEWALK, MODE_CROSSING_ROAD, MODE_ROAD_TO_SIDEWALK, MODE_CHECKING_TRAFFIC = range(5)
@@ -112,8 +113,10 @@ def moussaid_term(e, dist, dv, p: Interaction, theta_tol=0.0):
     """Angular interaction of Moussaid et al. 2009 as coded in forces.py:85-115 (ped-ped) and
     forces.py:241-270 (ped-obstacle).  ``e`` unit direction towards the other body (k components),
     ``dist`` the (possibly radius-reduced) distance, ``dv`` = v_self - v_other.
-    Returns (force[..., k], exposure[...]) where exposure is the jump of the lateral term if the sign
-    of theta (or the +-pi wrap) flipped and |theta| (or |raw|-pi) is within ``theta_tol``."""
+    Returns (force[..., k], exposure[...], magnitude[...]): exposure is the jump of the lateral term if
+    the sign of theta (or the +-pi wrap) flipped and |theta| (or |raw|-pi) is within ``theta_tol``;
+    magnitude = |f_v| + |f_theta| is the size of the term, the natural scale for the rounding error of a
+    sum of such terms."""
     D = p.lam * dv + e                                       # :85
     t, Dn = unit_and_norm(D)                                 # :86
     ang, raw = wrapped_angle_diff(e, t)                      # :94
@@ -132,7 +135,16 @@ def moussaid_term(e, dist, dv, p: Interaction, theta_tol=0.0):
             expo = np.where(near, 2.0 * np.abs(f_th), 0.0)
     else:
         expo = np.zeros_like(dist)
-    return F, expo
+    # Conditioning: d f/d theta = -2 (n B)^2 theta f.  fp32 cannot resolve theta finer than ~2^-22 rad (theta is
+    # the angle between two fp32-rounded directions), so ANY fp32 evaluation of this term carries a relative
+    # error of 2 (n B)^2 |theta| * 2^-22 on top of ordinary rounding; fast vehicles (B ~ 10) make that ~2e-5.
+    # The scale reported for a term is its magnitude times (1 + that amplification / 1e-5), so "1e-5 of the
+    # scale" means 1e-5 plus the unavoidable first-order fp32 angle noise (parity section).
+    with np.errstate(invalid="ignore", over="ignore"):
+        amp_v = 2.0 * np.square(p.n_prime * B) * np.abs(theta) * FP32_ANGLE_RESOLUTION / 1e-5
+        amp_t = 2.0 * np.square(p.n * B) * np.abs(theta) * FP32_ANGLE_RESOLUTION / 1e-5
+        mag = np.abs(f_v) * (1.0 + amp_v) + np.abs(f_th) * (1.0 + amp_t)
+    return F, expo, mag
 
 
 # --------------------------------------------------------------------------------------------------
@@ -159,11 +171,12 @@ def pedestrian_force(loc, vel, radius, p: Interaction, use_ped_radius=False, chu
       diff = loc_j - loc_i (3 components), e = diff/|diff| (zero-safe), dist = |diff| [- r_i - r_j],
       dv = v_i - v_j (forces.py:77), then ``moussaid_term``; F_i = sum_j (forces.py:117).
     ``rows`` = (i0, i1) restricts the output to a shard of pedestrians (all j are still visited).
-    Returns (F[(i1-i0),3], exposure[(i1-i0)])."""
+    Returns (F[(i1-i0),3], exposure[(i1-i0)], absum[(i1-i0)]) with absum_i = sum_j |f_ij|."""
     N = loc.shape[0]
     i0, i1 = (0, N) if rows is None else rows
     F = np.zeros((i1 - i0, 3))
     expo = np.zeros(i1 - i0)
+    absum = np.zeros(i1 - i0)
     idx = np.arange(N)
     for s in range(i0, i1, chunk):
         e_ = min(i1, s + chunk)
@@ -172,13 +185,15 @@ def pedestrian_force(loc, vel, radius, p: Interaction, use_ped_radius=False, chu
         dv = vel[s:e_, None, :] - vel[None, :, :]
         if use_ped_radius:
             dist = dist - (radius[s:e_, None] + radius[None, :])   # forces.py:80-82
-        f, ex = moussaid_term(e, dist, dv, p, theta_tol)
+        f, ex, mg = moussaid_term(e, dist, dv, p, theta_tol)
         off_diag = (idx[None, :] != np.arange(s, e_)[:, None])
         f = np.where(off_diag[..., None], f, 0.0)                  # drop j == i (select, so NaN-safe)
         ex = np.where(off_diag, ex, 0.0)
+        mg = np.where(off_diag, mg, 0.0)
         F[s - i0:e_ - i0] = f.sum(axis=1)
         expo[s - i0:e_ - i0] = np.nansum(ex, axis=1)
-    return F, expo
+        absum[s - i0:e_ - i0] = np.nansum(mg, axis=1)
+    return F, expo, absum
 
 
 # --------------------------------------------------------------------------------------------------
@@ -214,14 +229,15 @@ def border_force(loc, radius, crossing, borders, centers, lengths, a, b, use_ped
       z = 0 (:171-173); whole force zeroed where ``crossing`` (modes 2,3; :176-177);
       no borders -> zeros (:140-141).
     Looped over borders (vectorised over the pedestrians that keep each border).
-    Returns (F[n,3], exposure[n])."""
+    Returns (F[n,3], exposure[n], absum[n])."""
     N = loc.shape[0]
     i0, i1 = (0, N) if rows is None else rows
     n = i1 - i0
     F = np.zeros((n, 3))
     expo = np.zeros(n)
+    absum = np.zeros(n)
     if len(borders) == 0:
-        return F, expo
+        return F, expo, absum
     xy = loc[i0:i1, :2]
     rad = radius[i0:i1]
     centers = np.asarray(centers, dtype=np.float64).reshape(-1, 2)
@@ -247,6 +263,7 @@ def border_force(loc, radius, crossing, borders, centers, lengths, a, b, use_ped
         f = f_of(best)
         is_kept = np.isin(both, keep)
         F[both[is_kept], :2] += f[is_kept]
+        absum[both[is_kept]] += np.linalg.norm(f[is_kept], axis=1)
         if tie_rel > 0.0:
             on_edge = np.isin(both, edge)
             jump = np.where(on_edge, np.linalg.norm(f, axis=1), 0.0)
@@ -255,7 +272,8 @@ def border_force(loc, radius, crossing, borders, centers, lengths, a, b, use_ped
     mask = np.asarray(crossing[i0:i1], dtype=bool)
     F[mask] *= 0.0
     expo[mask] = 0.0
-    return F, expo
+    absum[mask] = 0.0
+    return F, expo, absum
 
 
 # --------------------------------------------------------------------------------------------------
@@ -269,14 +287,15 @@ def obstacle_force(loc, vel, radius, obstacles, obstacle_vel, p: Interaction, us
       e = (p-x)/|p-x|, dist = |p-x| [- r_i] (:233,237-238), dv = v_i - v_obs,k (:234; static: 0, :212-213);
       then ``moussaid_term`` with this force's own parameter set; sum; z = 0 (:279-281).
       ``obstacles`` None/empty -> zeros (:209-210).  No crossing mask.
-    Returns (F[n,3], exposure[n])."""
+    Returns (F[n,3], exposure[n], absum[n])."""
     N = loc.shape[0]
     i0, i1 = (0, N) if rows is None else rows
     n = i1 - i0
     F = np.zeros((n, 3))
     expo = np.zeros(n)
+    absum = np.zeros(n)
     if obstacles is None or len(obstacles) == 0:
-        return F, expo
+        return F, expo, absum
     xy = loc[i0:i1, :2]
     v2 = vel[i0:i1, :2]
     rad = radius[i0:i1]
@@ -300,17 +319,18 @@ def obstacle_force(loc, vel, radius, obstacles, obstacle_vel, p: Interaction, us
             if use_ped_radius:
                 dist = dist - rad[both]
             return moussaid_term(e, dist, v2[both] - obstacle_vel[k], p, theta_tol)
-        f, ex = f_of(best)
+        f, ex, mg = f_of(best)
         is_kept = np.isin(both, keep)
         F[both[is_kept], :2] += f[is_kept]
         expo[both[is_kept]] += np.nan_to_num(ex[is_kept])
+        absum[both[is_kept]] += np.nan_to_num(mg[is_kept])
         if tie_rel > 0.0:
             on_edge = np.isin(both, edge)
             jump = np.where(on_edge, np.linalg.norm(f, axis=1), 0.0)
             if tie.any():
                 jump = jump + np.where(tie, np.linalg.norm(f_of(alt)[0] - f, axis=1), 0.0)
             expo[both] += np.nan_to_num(jump)
-    return F, expo
+    return F, expo, absum
 
 
 # --------------------------------------------------------------------------------------------------
@@ -351,36 +371,44 @@ class Geometry:
 
 
 def tick_forces(loc, vel, waypoint, target_speed, radius, crossing, geom: Geometry, prm: OracleParams,
-                theta_tol=0.0, tie_rel=0.0, rows=None, chunk=256):
+                theta_tol=0.0, tie_rel=0.0, rows=None, chunk=256, diag=None):
     """Force part of PedestrianSimulation.tick (pedestrian_simulation.py:81): the enabled forces in the
     dict order acceleration, pedestrian, border, static, dynamic (:37-48).  Returns
-    (dict name -> (n,3), total (n,3), exposure (n,))."""
+    (dict name -> (n,3), total (n,3), exposure (n,)).  ``diag`` (a dict, optional) receives per force the
+    exposure and the absolute sum of the terms (the scale of the fp32 rounding error of that force)."""
     N = loc.shape[0]
     i0, i1 = (0, N) if rows is None else rows
     out = {}
     expo = np.zeros(i1 - i0)
     en = prm.enabled
+    if diag is None:
+        diag = {}
     if en["acceleration_force"]:
         out["acceleration_force"] = acceleration_force(loc, vel, waypoint, target_speed, prm.tau)[i0:i1]
+        mag = (np.abs(target_speed[i0:i1]) + np.linalg.norm(vel[i0:i1], axis=1)) / prm.tau
+        diag["acceleration_force"] = (np.zeros(i1 - i0), mag)
     if en["pedestrian_force"]:
-        f, ex = pedestrian_force(loc, vel, radius, prm.ped, prm.use_ped_radius, chunk, theta_tol, (i0, i1))
+        f, ex, ab = pedestrian_force(loc, vel, radius, prm.ped, prm.use_ped_radius, chunk, theta_tol, (i0, i1))
         out["pedestrian_force"] = f
-        expo += ex
+        diag["pedestrian_force"] = (ex, ab)
     if en["border_force"]:
-        f, ex = border_force(loc, radius, crossing, geom.borders, geom.border_centers, geom.border_lengths,
-                             prm.border_a, prm.border_b, prm.use_ped_radius, tie_rel, (i0, i1))
+        f, ex, ab = border_force(loc, radius, crossing, geom.borders, geom.border_centers, geom.border_lengths,
+                                 prm.border_a, prm.border_b, prm.use_ped_radius, tie_rel, (i0, i1))
         out["border_force"] = f
-        expo += ex
+        diag["border_force"] = (ex, ab)
     if en["static_obstacle_force"]:
-        f, ex = obstacle_force(loc, vel, radius, geom.static_obstacles, None, prm.static,
-                               prm.use_ped_radius, tie_rel, theta_tol, (i0, i1))
+        f, ex, ab = obstacle_force(loc, vel, radius, geom.static_obstacles, None, prm.static,
+                                   prm.use_ped_radius, tie_rel, theta_tol, (i0, i1))
         out["static_obstacle_force"] = f
-        expo += ex
+        diag["static_obstacle_force"] = (ex, ab)
     if en["dynamic_obstacle_force"]:
-        f, ex = obstacle_force(loc, vel, radius, geom.dynamic_obstacles, geom.dynamic_vel, prm.dynamic,
-                               prm.use_ped_radius, tie_rel, theta_tol, (i0, i1))
+        f, ex, ab = obstacle_force(loc, vel, radius, geom.dynamic_obstacles, geom.dynamic_vel, prm.dynamic,
+                                   prm.use_ped_radius, tie_rel, theta_tol, (i0, i1))
         out["dynamic_obstacle_force"] = f
+        diag["dynamic_obstacle_force"] = (ex, ab)
+    for ex, _ in diag.values():
         expo += ex
+    diag["total"] = (expo.copy(), sum(ab for _, ab in diag.values()))
     total = np.zeros((i1 - i0, 3))
     for name in FORCE_NAMES:           # same accumulation order as sum(map(...)) over the dict
         if name in out:

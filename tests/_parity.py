@@ -1,0 +1,49 @@
+"""Parity metric shared by the GPU tests.
+
+Tolerance (stated here once; BASELINE.json north_star: "<= 1e-5 relative in fp32"):
+
+  * new velocities v' -- the tick's output -- per pedestrian:  |dv'_i| <= RTOL * |v'_i| + RTOL * dt * exposure_i
+    (+ a 1e-12 floor for pedestrians whose v' is exactly 0);
+  * a force that is a SUM of terms (pedestrian, border, obstacle, total) per pedestrian:
+        |dF_i| <= RTOL * max(|F_i|, A_i) + exposure_i,      A_i = sum of the magnitudes of the summed terms,
+    i.e. relative to the quantity fp32 rounding of a sum is relative to (a pedestrian whose terms cancel
+    to ~0 cannot be matched to 1e-5 of ~0 by ANY fp32 evaluation order);
+  * exposure_i is the jump the reference function itself makes at a decision within fp32 noise of its
+    threshold (sign(theta) at 0, the +-pi wrap, argmin ties, strict-< culls), computed by the oracle in
+    float64 (oracle/sfm_oracle.py).  Pedestrians with non-zero exposure are counted and reported.
+
+NaN rows (coincident pedestrians, forces.py:97,105) must be NaN on both sides.
+"""
+import numpy as np
+
+RTOL = 1e-5
+THETA_TOL = 2e-5      # |theta| below this may flip sign in fp32 (angle error ~1e-7 rad, scaled by B)
+TIE_REL = 2e-6        # relative distance gap below which an argmin / cull decision may flip
+
+
+def check_force(name, got, ref, absum, expo, rtol=RTOL):
+    got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    nan_g, nan_r = np.isnan(got).any(axis=1), np.isnan(ref).any(axis=1)
+    assert np.array_equal(nan_g, nan_r), f"{name}: NaN rows differ (got {nan_g.sum()}, ref {nan_r.sum()})"
+    ok = ~nan_r
+    err = np.linalg.norm(got[ok] - ref[ok], axis=1)
+    scale = np.maximum(np.linalg.norm(ref[ok], axis=1), np.nan_to_num(absum[ok]))
+    allow = rtol * scale + np.nan_to_num(expo[ok]) * 1.001 + 1e-30
+    bad = err > allow
+    worst = float(np.max(err / np.maximum(scale, 1e-300))) if err.size else 0.0
+    assert not bad.any(), (f"{name}: {bad.sum()} of {ok.sum()} pedestrians out of tolerance; worst "
+                           f"err/scale {np.max((err / np.maximum(scale, 1e-300))[bad]):.3e} (rtol {rtol})")
+    return worst, int((np.nan_to_num(expo[ok]) > 0).sum())
+
+
+def check_velocity(got, ref, expo, dt, rtol=RTOL):
+    got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    nan_g, nan_r = np.isnan(got).any(axis=1), np.isnan(ref).any(axis=1)
+    assert np.array_equal(nan_g, nan_r), "v': NaN rows differ"
+    ok = ~nan_r
+    err = np.linalg.norm(got[ok] - ref[ok], axis=1)
+    nrm = np.linalg.norm(ref[ok], axis=1)
+    allow = rtol * nrm + dt * np.nan_to_num(expo[ok]) * 1.001 + 1e-12
+    bad = err > allow
+    assert not bad.any(), f"v': {bad.sum()} pedestrians out of tolerance, worst rel {np.max(err[bad] / np.maximum(nrm[bad], 1e-300)):.3e}"
+    return float(np.max(err / np.maximum(nrm, 1e-12))) if err.size else 0.0

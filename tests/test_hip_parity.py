@@ -1,0 +1,206 @@
+"""GPU parity tests: the HIP path, called through the C ABI (libsfm_hip via ctypes), against
+(a) the committed golden vectors produced by the reference itself and (b) the CPU oracle on seeded inputs.
+Run on the MI355X box with  python -m pytest tests -m gpu."""
+import numpy as np
+import pytest
+
+import _golden_io as gio
+import _parity as P
+from carla_social_force_model_amd import scenarios
+from carla_social_force_model_amd.config import default_sfm_config
+from carla_social_force_model_amd.engine import SfmEngine
+from oracle import c_oracle
+from oracle import sfm_oracle as O
+
+pytestmark = pytest.mark.gpu
+CASES = gio.list_cases()
+
+
+def _geom(c):
+    return O.Geometry(borders=c.borders, border_centers=c.border_centers, border_lengths=c.border_lengths,
+                      static_obstacles=c.static_obstacles, dynamic_obstacles=c.dynamic_obstacles,
+                      dynamic_vel=c.dynamic_vel)
+
+
+def _engine_for(c, cfg, tspeed):
+    eng = SfmEngine(cfg, c.dt)
+    if len(c.borders):
+        eng.set_borders(c.borders, c.border_centers, c.border_lengths)
+    eng.set_static_obstacles(c.static_obstacles)
+    eng.set_dynamic_obstacles(c.dynamic_obstacles, c.dynamic_vel)
+    eng.upload_state(c.loc, c.vel, c.waypoint, tspeed, c.radius, c.crossing)
+    return eng
+
+
+@pytest.mark.parametrize("path", CASES, ids=[p.split("/")[-1][:-4] for p in CASES])
+def test_golden_forces_and_velocities(path):
+    """Every golden case: each force, the total and v' against the REFERENCE's own outputs."""
+    c = gio.Case(path)
+    prm = O.OracleParams.from_config(c.cfg)
+    tspeed = c.z["mode_target_speed"]
+    diag = {}
+    with np.errstate(all="ignore"):
+        O.tick_forces(c.loc, c.vel, c.waypoint, tspeed, c.radius, c.crossing, _geom(c), prm,
+                      theta_tol=P.THETA_TOL, tie_rel=P.TIE_REL, diag=diag)
+    eng = _engine_for(c, c.cfg, tspeed)
+    try:
+        eng.tick(record=True)
+        for name in list(O.FORCE_NAMES) + ["total"]:
+            if c.has(name):
+                ex, ab = diag[name]
+                P.check_force(f"{c.name}/{name}", eng.forces(name), c.ref(name), ab, ex)
+        P.check_velocity(eng.velocities(), c.ref("new_vel"), diag["total"][0], c.dt)
+    finally:
+        eng.close()
+
+
+def test_arrived_matches_reference():
+    for path in CASES:
+        c = gio.Case(path)
+        eng = _engine_for(c, c.cfg, c.z["mode_target_speed"])
+        try:
+            got = eng.arrived(2.0)
+        finally:
+            eng.close()
+        d = np.linalg.norm(c.waypoint[:, :2] - c.loc[:, :2], axis=1)
+        sure = np.abs(d - 2.0) > 1e-5            # away from the strict-< edge
+        assert np.array_equal(got[sure], c.ref("arrived")[sure]), c.name
+
+
+@pytest.mark.parametrize("ipw", [1, 2, 4, 8])
+@pytest.mark.parametrize("n", [257, 1024, 3000])
+def test_pair_kernel_variants_vs_oracle(n, ipw, monkeypatch):
+    """All rows-per-wave variants of the pair kernel, ragged N (tail masking), against the C oracle."""
+    monkeypatch.setenv("SFM_IPW", str(ipw))
+    sc = scenarios.make_scenario(n, 900 + n)
+    cfg = default_sfm_config(("acceleration_force", "pedestrian_force"))
+    prm = O.OracleParams.from_config(cfg)
+    per, total, v_new, expo, absum = c_oracle.tick(sc.loc, sc.vel, sc.waypoint, sc.target_speed, sc.radius,
+                                                   np.zeros(n, bool), O.Geometry(), prm, 0.05, theta_tol=P.THETA_TOL)
+    eng = SfmEngine(cfg, 0.05)
+    try:
+        eng.upload_state(sc.loc, sc.vel, sc.waypoint, sc.target_speed, sc.radius, None)
+        eng.tick(record=True)
+        assert f"<{ipw}," in eng.kernel_variant()
+        P.check_force("total", eng.forces("total"), total, absum, expo)
+        P.check_velocity(eng.velocities(), v_new, expo, 0.05)
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("variant", ["radius", "z"])
+def test_radius_and_z_variants_vs_oracle(variant):
+    n = 700
+    sc = scenarios.make_scenario(n, 77, n_borders=30, n_static=12, n_dynamic=6, z_spread=1.0 if variant == "z" else 0.0,
+                                 border_len=(5.0, 20.0))
+    cfg = default_sfm_config()
+    cfg["use_ped_radius"] = variant == "radius"
+    prm = O.OracleParams.from_config(cfg)
+    geom = O.Geometry(sc.borders, sc.border_centers, sc.border_lengths, sc.static_obstacles, sc.dynamic_obstacles,
+                      sc.dynamic_vel)
+    diag = {}
+    with np.errstate(all="ignore"):
+        per, total, _ = O.tick_forces(sc.loc, sc.vel, sc.waypoint, sc.target_speed, sc.radius, np.zeros(n, bool), geom,
+                                      prm, theta_tol=P.THETA_TOL, tie_rel=P.TIE_REL, diag=diag)
+    v_new = O.new_velocities(sc.vel, total, sc.target_speed, 0.05)
+    eng = SfmEngine(cfg, 0.05)
+    try:
+        eng.set_borders(sc.borders, sc.border_centers, sc.border_lengths)
+        eng.set_static_obstacles(sc.static_obstacles)
+        eng.set_dynamic_obstacles(sc.dynamic_obstacles, sc.dynamic_vel)
+        eng.upload_state(sc.loc, sc.vel, sc.waypoint, sc.target_speed, sc.radius, None)
+        eng.tick(record=True)
+        for name in O.FORCE_NAMES:
+            P.check_force(name, eng.forces(name), per[name], diag[name][1], diag[name][0])
+        P.check_velocity(eng.velocities(), v_new, diag["total"][0], 0.05)
+    finally:
+        eng.close()
+
+
+def test_property_checks_at_baseline_size():
+    """BASELINE config 2 at full size (N=4096): properties the math implies, plus a
+    row-sampled comparison against the C oracle."""
+    sc, forces = scenarios.baseline_scenario("c2")
+    cfg = default_sfm_config(("pedestrian_force",))
+    eng = SfmEngine(cfg, 0.05)
+    try:
+        eng.upload_state(sc.loc, sc.vel, sc.waypoint, sc.target_speed, sc.radius, None)
+        eng.tick(record=True)
+        F = eng.forces("pedestrian_force")
+        assert np.isfinite(F).all()
+        # sum_i F_i = 0 (antisymmetry F_ij = -F_ji), relative to the sum of magnitudes
+        assert np.linalg.norm(F.sum(axis=0)) <= 1e-5 * np.linalg.norm(F, axis=1).sum()
+        # translation invariance (fp32-representable shift)
+        eng.upload_state(sc.loc + np.array([64.0, -32.0, 0.0]), sc.vel, sc.waypoint, sc.target_speed, sc.radius, None)
+        eng.tick(record=True)
+        F2 = eng.forces("pedestrian_force")
+        assert np.max(np.linalg.norm(F2 - F, axis=1)) <= 2e-4 * np.max(np.linalg.norm(F, axis=1))
+        # rows 0..255 and the last 256 against the oracle
+        prm = O.OracleParams.from_config(cfg)
+        for rows in ((0, 256), (sc.n - 256, sc.n)):
+            per, total, v_new, expo, absum = c_oracle.tick(sc.loc, sc.vel, sc.waypoint, sc.target_speed, sc.radius,
+                                                           np.zeros(sc.n, bool), O.Geometry(), prm, 0.05, rows=rows,
+                                                           theta_tol=P.THETA_TOL)
+            P.check_force("rows", F[rows[0]:rows[1]], total, absum, expo)
+    finally:
+        eng.close()
+
+
+def test_cap_velocity_properties():
+    """stateutils.cap_velocity: |v'| <= 1.3*v_target; zero target -> zero velocity."""
+    n = 512
+    sc = scenarios.make_scenario(n, 5)
+    sc.target_speed[::7] = 0.0
+    cfg = default_sfm_config(("acceleration_force", "pedestrian_force"))
+    eng = SfmEngine(cfg, 0.05)
+    try:
+        eng.upload_state(sc.loc, sc.vel, sc.waypoint, sc.target_speed, sc.radius, None)
+        eng.tick()
+        v = eng.velocities()
+        sp = np.linalg.norm(v, axis=1)
+        assert np.all(sp <= 1.3 * sc.target_speed * (1 + 1e-6) + 1e-12)
+        assert np.all(sp[::7] == 0.0)
+    finally:
+        eng.close()
+
+
+def test_multi_tick_resync_and_free_run():
+    """K ticks on the device (sfm_run with waypoint redraw): every tick re-synchronised against the oracle
+    stepping from the device's own previous fp32 state, then a short free-running window with a
+    growth-aware bound (crowd dynamics are chaotic)."""
+    n = 300
+    sc = scenarios.make_scenario(n, 4242, n_borders=10, n_static=6, border_len=(5.0, 20.0))
+    cfg = default_sfm_config(("acceleration_force", "pedestrian_force", "border_force", "static_obstacle_force"))
+    prm = O.OracleParams.from_config(cfg)
+    geom = O.Geometry(sc.borders, sc.border_centers, sc.border_lengths, sc.static_obstacles, [], None)
+    eng = SfmEngine(cfg, 0.05)
+    try:
+        eng.set_borders(sc.borders, sc.border_centers, sc.border_lengths)
+        eng.set_static_obstacles(sc.static_obstacles)
+        eng.upload_state(sc.loc, sc.vel, sc.waypoint, sc.target_speed, sc.radius, None)
+        eng.set_waypoint_stream(sc.seed, sc.world_side, 2.0)
+        loc, vel, wp = sc.loc.copy(), sc.vel.copy(), sc.waypoint.copy()
+        draws = np.zeros(n, dtype=np.int64)
+        free = (loc.copy(), vel.copy(), wp.copy(), draws.copy())
+        crossing = np.zeros(n, bool)
+        for k in range(25):
+            eng.run(1, redraw=True)
+            dloc, dvel, dwp = eng.state()
+            with np.errstate(all="ignore"):
+                oloc, ovel, owp, draws = O.free_step(loc, vel, wp, sc.target_speed, sc.radius, crossing, draws, geom, prm,
+                                                     0.05, 2.0, sc.seed, sc.world_side, round_f32=False)
+                free = O.free_step(*free[:3], sc.target_speed, sc.radius, crossing, free[3], geom, prm, 0.05, 2.0,
+                                   sc.seed, sc.world_side)
+            # re-sync: one-tick error from identical state
+            assert np.max(np.abs(dvel - ovel)) <= 5e-5 * np.max(np.abs(ovel)), f"tick {k}"
+            assert np.max(np.abs(dloc - oloc)) <= 1e-6 * max(1.0, np.max(np.abs(oloc))) + 1e-6, f"tick {k}"
+            sure = np.abs(np.linalg.norm(wp[:, :2] - loc[:, :2], axis=1) - 2.0) > 1e-4
+            assert np.allclose(dwp[sure], owp[sure, :2], rtol=0, atol=1e-4), f"waypoints at tick {k}"
+            assert np.array_equal(eng.draw_counts()[sure], draws[sure])
+            loc, vel = dloc, dvel                               # continue from the device's fp32 state
+            wp = np.concatenate([dwp, np.zeros((n, 1))], axis=1)
+            draws = eng.draw_counts().astype(np.int64)
+        # free run: error may grow, but stays small over 25 ticks
+        assert np.median(np.linalg.norm(dloc - free[0], axis=1)) < 1e-3
+    finally:
+        eng.close()

@@ -1,0 +1,157 @@
+"""CPU tests of the host-side mirror of the reference interface: mode FSM, PedState layout and accessors,
+config reading (bug-compatible), gap acceptance, geometry/scenario generators, shard arithmetic."""
+import numpy as np
+import pytest
+
+from carla_social_force_model_amd import scenarios
+from carla_social_force_model_amd.check_traffic import check_traffic
+from carla_social_force_model_amd.config import default_sfm_config, load_sfm_config
+from carla_social_force_model_amd.engine import params_from_config
+from carla_social_force_model_amd.ped_mode_manager import PedMode, PedModeManager
+from carla_social_force_model_amd.pedestrian_state import PED_STATE_DTYPE, PedState
+from carla_social_force_model_amd.stepper import shard_bounds
+
+
+def test_record_layout_is_the_reference_layout():
+    dt = np.dtype(PED_STATE_DTYPE)
+    assert dt.itemsize == 132
+    assert {k: dt.fields[k][1] for k in dt.names} == {'name': 0, 'id': 32, 'loc': 36, 'vel': 60, 'next_waypoint': 84,
+                                                      'mode': 108, 'radius': 116, 'target_speed': 124}
+
+
+def test_mode_fsm_transitions():
+    m = PedModeManager("p", 1.2, PedMode.WALKING_SIDEWALK, 1.5, 1.0)
+    assert m.target_speed == 1.2 and m.crossing_speed == pytest.approx(1.8)
+    m.set_mode(PedMode.CROSSING_ROAD)                 # diverted: look first
+    assert m.current_mode == PedMode.CHECKING_TRAFFIC and m.target_speed == 0
+    m.set_mode(PedMode.CROSSING_ROAD)
+    assert m.current_mode == PedMode.CROSSING_ROAD and m.target_speed == pytest.approx(1.8)
+    m.set_mode(PedMode.WALKING_SIDEWALK)              # diverted: still on the road, keeps crossing speed
+    assert m.current_mode == PedMode.ROAD_TO_SIDEWALK and m.target_speed == pytest.approx(1.8)
+    m.set_mode(PedMode.WALKING_SIDEWALK)
+    assert m.current_mode == PedMode.WALKING_SIDEWALK and m.target_speed == 1.2
+    m.tick(10.0)
+    m.set_mode(PedMode.IDLE)
+    assert m.target_speed == 0 and m.next_mode_time == 15.0
+    m.tick(14.9)
+    assert m.current_mode == PedMode.IDLE
+    m.tick(15.0)
+    assert m.current_mode == PedMode.WALKING_SIDEWALK and m.target_speed == 1.2
+    # the constructor does not run the initial mode's entry action
+    assert PedModeManager("q", 1.0, PedMode.IDLE, 1.5, 1.0).target_speed == 1.0
+
+
+def _ped(i, mode=PedMode.WALKING_SIDEWALK):
+    mm = PedModeManager(f"ped_{i}", 1.0 + 0.1 * i, mode, 1.5, 1.5)
+    return (f"ped_{i}", 100 + i, [i, 2.0 * i, 0.0], [0.1, 0.2, 0.0], [10.0, 10.0, 0.0], mm, 0.3, 1.0 + 0.1 * i)
+
+
+def test_pedstate_bookkeeping():
+    ps = PedState({})
+    assert ps.state is None and ps.max_speed_factor == 1.3
+    for i in range(40):                                # crosses the growth boundary
+        ps.add_pedestrian(_ped(i))
+    assert ps.size() == 40 and ps.state.dtype.itemsize == 132
+    assert np.allclose(ps.loc()[7], [7, 14, 0]) and ps.walker_id()[7] == 107 and ps.name()[7] == "ped_7"
+    ps.update_state(107, [1.0, 1.0, 0.5], [0.0, 0.0, 0.0])
+    assert np.allclose(ps.loc()[7], [1, 1, 0.5]) and np.allclose(ps.speeds()[7], 0)
+    ps.update_next_waypoint("ped_3", ([5.0, 5.0, 0.0], True))
+    assert ps.mode()[3].current_mode == PedMode.CHECKING_TRAFFIC
+    ps.apply_current_mode()
+    assert ps.target_speed()[3] == 0 and ps.target_speed()[4] == pytest.approx(1.4)
+    assert np.allclose(ps.max_speed(), 1.3 * ps.target_speed())
+    ps.mode()[5].set_mode(PedMode.CROSSING_ROAD); ps.mode()[5].set_mode(PedMode.CROSSING_ROAD)
+    assert ps.crossing_mask().sum() == 1 and ps.crossing_mask()[5]
+    ps.remove_pedestrian("ped_0")
+    assert ps.size() == 39 and ps.name()[0] == "ped_1"
+    with pytest.raises(IndexError):
+        ps.update_next_waypoint("nobody", ([0, 0, 0], False))
+    d = ps.desired_directions()
+    assert d.shape == (39, 3) and np.allclose(np.linalg.norm(d[:, :2], axis=1), 1) and np.all(d[:, 2] == 0)
+    ps.record_current_state(0.5)
+    snap = ps.get_all_states()[0.5]
+    assert snap['mode'][4] == PedMode.CROSSING_ROAD and snap.shape == (39,)
+    view = ps.state[['id', 'vel']]                     # the get_new_velocities view writes through
+    view['vel'] = np.ones((39, 3))
+    assert np.all(ps.vel() == 1.0)
+    loc, vel, wp, ts, rad, cm = ps.numeric_columns()
+    assert loc.flags['C_CONTIGUOUS'] and loc.shape == (39, 3) and cm.dtype == bool
+
+
+def test_config_surface_and_bug_compat():
+    cfg = load_sfm_config()
+    assert cfg == default_sfm_config()
+    p = params_from_config(cfg, 0.05)
+    assert p.tau == 0.5 and p.max_speed_factor == pytest.approx(1.3) and list(p.enabled) == [1] * 5
+    assert p.pedestrian.A == 4.5 and p.static_obstacle.A == 15 and p.dynamic_obstacle.perception_threshold == 50
+    assert p.border_a == 6.0 and p.border_b == pytest.approx(0.3)
+    cfg["acceleration_force"]["tau"] = 0.9
+    cfg["max_speed_multiplier"] = 2.0
+    assert params_from_config(cfg, 0.05).tau == 0.5                        # file key ignored, like the reference
+    q = params_from_config(cfg, 0.05, honour_file_keys=True)                # documented opt-in
+    assert q.tau == pytest.approx(0.9) and q.max_speed_factor == 2.0
+    cfg["goal_force"] = {"tau": 0.25}
+    assert params_from_config(cfg, 0.05).tau == 0.25
+    bad = default_sfm_config()
+    del bad["pedestrian_force"]
+    with pytest.raises(KeyError):
+        params_from_config(bad, 0.05)
+    bad = default_sfm_config()
+    bad["forces"]["ped_repulsive_force"] = True
+    with pytest.raises(AttributeError):
+        params_from_config(bad, 0.05)
+    bad = default_sfm_config()
+    bad["border_force"] = {}
+    p = params_from_config(bad, 0.05)
+    assert p.border_a == 3.0 and p.border_b == pytest.approx(0.1)           # code-side defaults (forces.py:135-136)
+
+
+def test_check_traffic_closed_form():
+    mm = PedModeManager("p", 1.0, PedMode.WALKING_SIDEWALK, 1.5, 1.0)        # crossing speed 1.5, margin 1 s
+    ped = {"loc": np.array([0.0, -3.0, 0.0]), "next_waypoint": np.array([0.0, 3.0, 0.0]), "mode": mm}
+    ring = np.zeros((6, 2))
+    ext = [np.array([2.0, 1.0])]
+    # vehicle far to the left, driving right at 10 m/s: reaches x=0 after ~2 s, pedestrian is there at 2 s -> wait
+    assert check_traffic(ped, [(np.array([-22.0, 0.0]), ring)], [np.array([10.0, 0.0])], ext) is False
+    # same vehicle driving away -> no intersection -> go
+    assert check_traffic(ped, [(np.array([-22.0, 0.0]), ring)], [np.array([-10.0, 0.0])], ext) is True
+    # stationary vehicle on the path: intersection exists but speed 0 is skipped (check_traffic.py:49)
+    assert check_traffic(ped, [(np.array([0.0, 0.0]), ring)], [np.array([0.0, 0.0])], ext) is True
+    # vehicle passes long before the pedestrian arrives
+    assert check_traffic(ped, [(np.array([-3.0, 0.0]), ring)], [np.array([30.0, 0.0])], ext) is True
+    # negative safety margin: cross without looking
+    mm.crossing_safety_margin = -1
+    assert check_traffic(ped, [(np.array([-22.0, 0.0]), ring)], [np.array([10.0, 0.0])], ext) is True
+
+
+def test_scenario_generators_follow_reference_formats():
+    sc = scenarios.make_scenario(100, 3, n_borders=5, n_static=4, n_dynamic=3)
+    assert sc.loc.shape == (100, 3) and np.all(sc.loc[:, 2] == 0)
+    for a in (sc.loc, sc.vel, sc.waypoint, sc.target_speed):
+        assert np.array_equal(a, a.astype(np.float32).astype(np.float64))      # fp32-representable
+    d = np.linalg.norm(sc.loc[:, None, :2] - sc.loc[None, :, :2], axis=-1) + np.eye(100)
+    assert d.min() > 0.3                                                         # jittered grid: no coincident peds
+    line, c, sl = scenarios.straight_border([0.0, 0.0], [10.0, 0.0])
+    assert len(line) == 100 and np.allclose(c, line[50]) and sl == pytest.approx(10.0)
+    ring = scenarios.ellipse_ring(np.array([0.0, 0.0]), 0.0, 2.4, 1.0)
+    assert len(ring) == 68 and np.allclose(ring[0], [2.4 * np.sqrt(2), 0.0], atol=1e-6)
+    assert len(scenarios.ellipse_ring(np.array([0.0, 0.0]), 0.3, 0.1, 0.1)) == 6
+    info = sc.section_info()
+    assert info.shape == (5, 2) and info.dtype == object
+    sc2 = scenarios.make_scenario(100, 3, n_borders=5, n_static=4, n_dynamic=3)
+    assert np.array_equal(sc.loc, sc2.loc) and np.array_equal(sc.borders[2], sc2.borders[2])
+    for name, kw in scenarios.BASELINE_CONFIGS.items():
+        assert kw["seed"] == 1000 + int(name[1])
+
+
+def test_shard_bounds_cover_everything_once():
+    for n, world in ((4096, 1), (4096, 8), (1000, 4), (65536, 4), (300, 2)):
+        n_pad = -(-n // 256) * 256
+        rows = []
+        for r in range(world):
+            lo, hi, chunk = shard_bounds(n, n_pad, r, world)
+            assert chunk * world == n_pad and 0 <= lo <= hi <= n
+            rows += list(range(lo, hi))
+        assert rows == list(range(n))
+    with pytest.raises(ValueError):
+        shard_bounds(100, 256, 0, 3)

@@ -88,3 +88,18 @@ def test_config_bug_compat():
     assert p.tau == 0.25 and p.max_speed_factor == 2.0
     with pytest.raises(KeyError):
         O.OracleParams.from_config({"forces": {"pedestrian_force": True}})
+
+
+@pytest.mark.parametrize("path", CASES, ids=[p.split("/")[-1][:-4] for p in CASES])
+def test_c_oracle_matches_golden(path):
+    """The C/OpenMP restatement (large-N oracle and CPU baseline) is gated on the same vectors."""
+    from oracle import c_oracle
+    c = gio.Case(path)
+    prm = O.OracleParams.from_config(c.cfg)
+    tspeed = c.z["mode_target_speed"]
+    per, total, v_new, _, _ = c_oracle.tick(c.loc, c.vel, c.waypoint, tspeed, c.radius, c.crossing, _geom(c), prm, c.dt,
+                                         nthreads=1)
+    for name in per:
+        _close(per[name], c.ref(name), f"{c.name}/{name}")
+    _close(total, c.ref("total"), f"{c.name}/total")
+    _close(v_new, c.ref("new_vel"), f"{c.name}/new_vel")
