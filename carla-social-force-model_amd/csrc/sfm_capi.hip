@@ -13,8 +13,10 @@
 #include <vector>
 
 namespace sfm {
-hipError_t launch_tick(int ipw, bool z3, bool rad, const TickArgs& a, hipStream_t st);
+hipError_t launch_tick(int ipw, int team, bool z3, bool rad, const TickArgs& a, hipStream_t st);
 hipError_t launch_arrived(const float4* pk, const float4* own, int N, float thr2, uint8_t* mask, hipStream_t st);
+hipError_t launch_sym_tick(const TickArgs& a, const SymArgs& sa, hipStream_t st);
+int probe_dpp_direction(hipStream_t st);
 }  // namespace sfm
 
 using namespace sfm;
@@ -50,6 +52,16 @@ struct SfmHandle {
     bool rec_valid = false;
     DevGeo borders, statics, dynamics;
 
+    // symmetric pedestrian-force path (single shard, planar, no radius)
+    float2* slab = nullptr;
+    int* tile_flag = nullptr;
+    int n_t = 0;
+    size_t slab_cap = 0;
+    int tile_cap = 0;
+    int dpp_dir = 0;
+    int sym_mode = -1;                     // SFM_SYM: 0 off, 1 on when eligible, -1 auto
+    bool used_sym = false;
+
     uint32_t seed = 0;
     float world_side = 0.f, arrive_thr = 2.0f;
 
@@ -57,7 +69,7 @@ struct SfmHandle {
     int timed_ticks = 0, timed_launches = 0;
     bool timing_valid = false;
     int ipw_last = 0;
-    int ipw_override = 0;
+    int ipw_override = 0, team_override = 0;
     char variant[64] = "none";
 };
 
@@ -135,6 +147,11 @@ int sfm_create(const SfmParams* params, int device_id, SfmHandle** out) {
     }
     const char* ov = getenv("SFM_IPW");
     if (ov) h->ipw_override = atoi(ov);
+    ov = getenv("SFM_TEAM");
+    if (ov) h->team_override = atoi(ov);
+    ov = getenv("SFM_SYM");
+    if (ov) h->sym_mode = atoi(ov);
+    h->dpp_dir = probe_dpp_direction(nullptr);
     *out = h;
     return SFM_OK;
 }
@@ -157,6 +174,8 @@ int sfm_destroy(SfmHandle* h) {
     if (h->arrived) hipFree(h->arrived);
     if (h->draws) hipFree(h->draws);
     if (h->rec) hipFree(h->rec);
+    if (h->slab) hipFree(h->slab);
+    if (h->tile_flag) hipFree(h->tile_flag);
     free_geo(h->borders); free_geo(h->statics); free_geo(h->dynamics);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
@@ -262,7 +281,10 @@ int sfm_upload_state(SfmHandle* h, int N, const float* x, const float* y, const 
     h->N = N; h->N_pad = n_pad; h->z3 = z3; h->rad = rad;
     h->i_begin = 0; h->i_end = N; h->cur = 0; h->rec_valid = false; h->timing_valid = false;
     if (N == 0) return SFM_OK;
-    std::vector<float4> pk((size_t)n_pad, make_float4(0.f, 0.f, 0.f, 0.f)), own((size_t)n_pad, make_float4(0.f, 0.f, 0.f, 0.f));
+    std::vector<float4> pk((size_t)n_pad), own((size_t)n_pad, make_float4(0.f, 0.f, 0.f, 0.f));
+    // padding rows are ghost pedestrians parked far away at distinct positions: every interaction with them
+    // underflows to exactly 0 (exp2 of ~ -1e16), so the symmetric kernel needs no masking
+    for (int i = N; i < n_pad; ++i) pk[i] = make_float4(3.0e15f + 1.0e12f * (float)(i - N + 1), 3.0e15f, 0.f, 0.f);
     std::vector<float2> zv((size_t)n_pad, make_float2(0.f, 0.f));
     std::vector<float> rr((size_t)n_pad, 0.f);
     std::vector<uint8_t> cm((size_t)n_pad, 0);
@@ -281,6 +303,14 @@ int sfm_upload_state(SfmHandle* h, int N, const float* x, const float* y, const 
     HIP_TRY(h, hipMemcpy(h->radius, rr.data(), sizeof(float) * (size_t)n_pad, hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->crossing, cm.data(), (size_t)n_pad, hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemset(h->draws, 0, sizeof(uint32_t) * (size_t)n_pad));
+    // slab of the symmetric path: n_t x (n_t*64) float2, only while it stays modest (<= 1 GiB)
+    h->n_t = (N + WAVE - 1) / WAVE;
+    const size_t need = (size_t)h->n_t * (size_t)h->n_t * WAVE;
+    if (!z3 && !rad && h->dpp_dir != 0 && h->sym_mode != 0 && need * sizeof(float2) <= ((size_t)1 << 30)) {
+        if (need > h->slab_cap) { HIP_TRY(h, dev_realloc(h->slab, need)); h->slab_cap = need; }
+        if (h->n_t > h->tile_cap) { HIP_TRY(h, dev_realloc(h->tile_flag, (size_t)h->n_t)); h->tile_cap = h->n_t; }
+        HIP_TRY(h, hipMemset(h->tile_flag, 0, sizeof(int) * (size_t)h->n_t));
+    }
     return SFM_OK;
 }
 
@@ -300,14 +330,19 @@ int sfm_set_waypoint_stream(SfmHandle* h, uint32_t seed, float world_side, float
     return SFM_OK;
 }
 
-static int pick_ipw(const SfmHandle* h, int n_local) {
+// Launch shape: rows per wave (IPW) and waves sharing a row set (TEAM).  The pair body is one long dependent
+// chain, so a SIMD needs ~16 independent chains (waves x IPW) to issue every cycle; small shards get there by
+// splitting the j range over the 4 waves of a workgroup (TEAM 4), large ones by more rows per wave.
+static void pick_shape(const SfmHandle* h, int n_local, int* ipw, int* team) {
+    int t = (n_local < 16384) ? 4 : 1;
+    if (h->team_override == 1 || h->team_override == 4) t = h->team_override;
+    int w;
+    if (t == 4) w = (n_local >= 2048) ? 4 : (n_local >= 1024 ? 2 : 1);
+    else w = (n_local >= 4 * 2048) ? 4 : (n_local >= 2 * 2048 ? 2 : 1);
     if (h->ipw_override == 1 || h->ipw_override == 2 || h->ipw_override == 4 || h->ipw_override == 8)
-        return h->ipw_override;
-    // keep >= 2 waves on each of the 1024 SIMDs when the shard allows it
-    if (n_local >= 8 * 2048) return 8;
-    if (n_local >= 4 * 2048) return 4;
-    if (n_local >= 2 * 2048) return 2;
-    return 1;
+        w = h->ipw_override;
+    *ipw = w;
+    *team = t;
 }
 
 static void fill_args(SfmHandle* h, TickArgs& a, uint32_t flags) {
@@ -353,17 +388,29 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags) {
     if (h->N == 0 || ticks == 0) return SFM_OK;        // tick() early-out (pedestrian_simulation.py:60-61)
     if (!h->pk[0]) return fail(h, SFM_ERR_STATE, "sfm_upload_state has not been called");
     const int n_local = h->i_end - h->i_begin;
-    const int ipw = pick_ipw(h, n_local);
+    int ipw = 1, team = 1;
+    pick_shape(h, n_local, &ipw, &team);
     h->ipw_last = ipw;
-    snprintf(h->variant, sizeof(h->variant), "sfm_tick_kernel<%d,%s,%s>", ipw, h->z3 ? "true" : "false",
-             h->rad ? "true" : "false");
+    // symmetric path: whole crowd on this handle, planar, no radius; auto mode wants >= 4 tiles
+    const size_t need = (size_t)h->n_t * (size_t)h->n_t * WAVE;
+    const bool sym = !h->z3 && !h->rad && h->i_begin == 0 && h->i_end == h->N && h->slab && need <= h->slab_cap &&
+                     h->dpp_dir != 0 && h->prm.enabled[SFM_FORCE_PEDESTRIAN] &&
+                     (h->sym_mode == 1 || (h->sym_mode < 0 && h->N >= 256));
+    h->used_sym = sym;
+    if (sym) snprintf(h->variant, sizeof(h->variant), "sfm_pair_sym_kernel+sfm_sym_epilogue_kernel");
+    else snprintf(h->variant, sizeof(h->variant), "sfm_tick_kernel<%d,%s,%s,%d>", ipw, h->z3 ? "true" : "false",
+                  h->rad ? "true" : "false", team);
     HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
     int launches = 0;
     for (int t = 0; t < ticks; ++t) {
         TickArgs a;
         fill_args(h, a, flags);
-        if (n_local > 0) {
-            HIP_TRY(h, launch_tick(ipw, h->z3, h->rad, a, h->stream));
+        if (sym) {
+            SymArgs sa{h->slab, h->tile_flag, h->n_t, h->n_t * WAVE, h->dpp_dir, getenv("SFM_DEBUG_STEPS") ? atoi(getenv("SFM_DEBUG_STEPS")) : -1};
+            HIP_TRY(h, launch_sym_tick(a, sa, h->stream));
+            launches += 2;
+        } else if (n_local > 0) {
+            HIP_TRY(h, launch_tick(ipw, team, h->z3, h->rad, a, h->stream));
             ++launches;
         }
         h->cur ^= 1;

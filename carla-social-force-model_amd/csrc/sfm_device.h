@@ -57,4 +57,14 @@ struct TickArgs {
     Geo borders, statics, dynamics;
 };
 
+// Symmetric (antisymmetry-exploiting) pedestrian-force path, single shard only.
+struct SymArgs {
+    float2* slab;        // [n_t][stride]: slab[u][i] = -A-less force on pedestrian i from all pedestrians of tile u
+    int* tile_flag;      // [n_t]: a coincident valid pair touches this tile -> exact recompute in the epilogue
+    int n_t;             // number of 64-pedestrian tiles
+    int stride;          // n_t * 64
+    int dir;             // lane direction of the DPP wavefront rotate (+1: lane l receives lane l+1), calibrated at init
+    int debug_steps;     // < 0: normal; >= 0: run only this many systolic steps per wave (timing probe, wrong results)
+};
+
 }  // namespace sfm

@@ -49,6 +49,27 @@ __device__ __forceinline__ float atan2_poly(float s, float c) {
     return copysignf(phi, s);
 }
 
+// atan2(s, c) for a UNIT vector (s, c) (2-D fast path: both directions are normalised), half-angle form:
+//   tan(theta/2) = s / (1 + c)  ->  theta = 2 atan(s / (1 + |c|)) for c >= 0, sign(s)*pi - that for c < 0.
+// The ratio is in [-1, 1] for every quadrant, so there is no octant swap, and theta = r * P(r^2) keeps
+// full RELATIVE precision for small angles (head-on encounters, where the force is largest).
+// 9-coefficient minimax fit of 2*atan(r)/r on [0,1], relative error 1.4e-8.  (0,0) -> 0.
+__device__ __forceinline__ float atan2_unit(float s, float c) {
+    const float r = s * rcp(1.0f + fabsf(c));
+    const float z = r * r;
+    float p = 0.0058070349296077258f;
+    p = fmaf(p, z, -0.032565738120124484f);
+    p = fmaf(p, z, 0.086078288980656448f);
+    p = fmaf(p, z, -0.15067314789328404f);
+    p = fmaf(p, z, 0.21309337545480259f);
+    p = fmaf(p, z, -0.28414262998659057f);
+    p = fmaf(p, z, 0.39986107686183325f);
+    p = fmaf(p, z, -0.66666187889991357f);
+    p = fmaf(p, z, 1.9999999727316076f);
+    const float a = p * r;
+    return (c < 0.0f) ? (copysignf(3.14159265358979324f, s) - a) : a;
+}
+
 // One Moussaid interaction (forces.py:85-115 / :241-270) without the common factor -A:
 //   (dx,dy,dz) = other - self, (dvx,dvy,dvz) = v_self - v_other, rsum = radii to subtract.
 // Adds e1*t + g*n to (gx,gy,gz), n = (-t_y, t_x, 0).
@@ -92,7 +113,8 @@ __device__ __forceinline__ void moussaid(const IxConst& c, float dx, float dy, f
         const float deff = RAD ? d - rsum : d;
         aL = deff * (rD * c.c1);
     }
-    const float ang = atan2_poly<EXACT>(sn, cs);                      // == wrapped atan2 difference (stateutils.py:104-112)
+    // == wrapped atan2 difference (stateutils.py:104-112); planar fast path: (sn, cs) is a unit vector
+    const float ang = (EXACT || Z3) ? atan2_poly<EXACT>(sn, cs) : atan2_unit(sn, cs);
     const float theta = fmaf(-c.eg, Dn, ang);                         // forces.py:101
     const float q = Dn * theta;
     const float q2 = q * q;
@@ -241,16 +263,25 @@ __device__ __forceinline__ void obstacle_force(const Geo& g, const IxConst& c, b
 // ------------------------------------------------------------------------------------------------------
 // the fused tick
 // ------------------------------------------------------------------------------------------------------
-template <int IPW, bool Z3, bool RAD>
+// TEAM = number of waves that share the same IPW pedestrians:
+//   TEAM 1: every wave has its own rows; the workgroup stages j-tiles through LDS (large shards);
+//   TEAM 4: the 4 waves of the workgroup share the rows and split the j range (wave w takes records
+//           64*(4s + w) ...), each streaming its own coalesced float4 per lane straight from L2 with a
+//           register prefetch; partial sums meet in LDS.  This multiplies the number of independent pair
+//           chains per SIMD by 4 -- what a small crowd (N = 4096: only 4 rows per SIMD) needs to hide the
+//           latency of the dependent rsq -> rsq -> rcp -> exp chain.
+template <int IPW, bool Z3, bool RAD, int TEAM>
 __global__ __launch_bounds__(BLOCK) void sfm_tick_kernel(const TickArgs a) {
-    __shared__ __attribute__((aligned(16))) float4 s_pk[2][TILE_J];
-    __shared__ __attribute__((aligned(16))) float2 s_zv[Z3 ? 2 : 1][Z3 ? TILE_J : 1];
-    __shared__ float s_rad[RAD ? 2 : 1][RAD ? TILE_J : 1];
+    constexpr bool STAGED = (TEAM == 1);
+    __shared__ __attribute__((aligned(16))) float4 s_pk[STAGED ? 2 : 1][STAGED ? TILE_J : 1];
+    __shared__ __attribute__((aligned(16))) float2 s_zv[(STAGED && Z3) ? 2 : 1][(STAGED && Z3) ? TILE_J : 1];
+    __shared__ float s_rad[(STAGED && RAD) ? 2 : 1][(STAGED && RAD) ? TILE_J : 1];
+    __shared__ float s_part[WAVES_PER_BLOCK][IPW][3];      // TEAM 4: per-wave partial pedestrian forces
 
     const int tid = threadIdx.x;
     const int lane = tid & (WAVE - 1);
     const int wave = uniform(tid >> 6);
-    const int ibase = a.i_begin + (blockIdx.x * WAVES_PER_BLOCK + wave) * IPW;   // uniform
+    const int ibase = a.i_begin + (TEAM == 1 ? (blockIdx.x * WAVES_PER_BLOCK + wave) : blockIdx.x) * IPW;   // uniform
     const int N = a.N;
 
     // own rows -> SGPRs (clamped so inactive tail slots read a valid row; they never store)
@@ -271,70 +302,102 @@ __global__ __launch_bounds__(BLOCK) void sfm_tick_kernel(const TickArgs a) {
 
     if (a.en_ped && N > 1) {
         float flag = 0.0f;                       // max rsq(d2) over valid pairs: coincidence detector
-        const int ntiles = (N + TILE_J - 1) / TILE_J;
-        float4 r_pk = a.pk_cur[tid];
-        float2 r_zv = make_float2(0.f, 0.f);
-        float r_rad = 0.0f;
-        if (Z3) r_zv = a.zv_cur[tid];
-        if (RAD) r_rad = a.radius[tid];
-        s_pk[0][tid] = r_pk;
-        if (Z3) s_zv[0][tid] = r_zv;
-        if (RAD) s_rad[0][tid] = r_rad;
-        __syncthreads();
-        for (int t = 0; t < ntiles; ++t) {
-            const int buf = t & 1;
-            if (t + 1 < ntiles) {                // prefetch the next tile while this one is consumed
-                r_pk = a.pk_cur[(t + 1) * TILE_J + tid];
-                if (Z3) r_zv = a.zv_cur[(t + 1) * TILE_J + tid];
-                if (RAD) r_rad = a.radius[(t + 1) * TILE_J + tid];
-            }
-#pragma unroll 1
-            for (int s = 0; s < TILE_J / WAVE; ++s) {
-                const int j0 = t * TILE_J + s * WAVE;                    // uniform
-                if (j0 >= N) break;
-                const float4 pj = s_pk[buf][s * WAVE + lane];
-                float zj = 0.0f, vzj = 0.0f, rj = 0.0f;
-                if (Z3) { const float2 zz = s_zv[buf][s * WAVE + lane]; zj = zz.x; vzj = zz.y; }
-                if (RAD) rj = s_rad[buf][s * WAVE + lane];
-                const bool clean = (j0 + WAVE <= N) && (ibase + IPW <= j0 || ibase >= j0 + WAVE);   // uniform
-                if (clean) {
+
+        // 64 pairs x IPW rows: lane's record pj against the wave's rows
+        auto step = [&](int j0, const float4 pj, float zj, float vzj, float rj) {
+            const bool clean = (j0 + WAVE <= N) && (ibase + IPW <= j0 || ibase >= j0 + WAVE);   // uniform
+            if (clean) {
 #pragma unroll
-                    for (int k = 0; k < IPW; ++k) {
-                        float rinv;
-                        moussaid<Z3, RAD, Z3>(a.ped, pj.x - xi[k], pj.y - yi[k], zj - zi[k], vxi[k] - pj.z,
-                                              vyi[k] - pj.w, vzi[k] - vzj, ri[k] + rj, gx[k], gy[k], gz[k], rinv);
-                        flag = fmaxf(flag, rinv);
-                    }
-                } else {                                                  // tile holds the diagonal or the tail
-                    const int j = j0 + lane;
+                for (int k = 0; k < IPW; ++k) {
+                    float rinv;
+                    moussaid<Z3, RAD, Z3>(a.ped, pj.x - xi[k], pj.y - yi[k], zj - zi[k], vxi[k] - pj.z,
+                                          vyi[k] - pj.w, vzi[k] - vzj, ri[k] + rj, gx[k], gy[k], gz[k], rinv);
+                    flag = fmaxf(flag, rinv);
+                }
+            } else {                                                  // step holds the diagonal or the tail
+                const int j = j0 + lane;
 #pragma unroll
-                    for (int k = 0; k < IPW; ++k) {
-                        float cx = 0.0f, cy = 0.0f, cz = 0.0f, rinv;
-                        moussaid<Z3, RAD, Z3>(a.ped, pj.x - xi[k], pj.y - yi[k], zj - zi[k], vxi[k] - pj.z,
-                                              vyi[k] - pj.w, vzi[k] - vzj, ri[k] + rj, cx, cy, cz, rinv);
-                        const bool valid = (j < N) & (j != ibase + k);   // all_diffs drops j == i (stateutils.py:41-49)
-                        gx[k] += valid ? cx : 0.0f;                       // select, so a NaN on the diagonal never leaks
-                        gy[k] += valid ? cy : 0.0f;
-                        if (Z3) gz[k] += valid ? cz : 0.0f;
-                        flag = fmaxf(flag, valid ? rinv : 0.0f);
-                    }
+                for (int k = 0; k < IPW; ++k) {
+                    float cx = 0.0f, cy = 0.0f, cz = 0.0f, rinv;
+                    moussaid<Z3, RAD, Z3>(a.ped, pj.x - xi[k], pj.y - yi[k], zj - zi[k], vxi[k] - pj.z,
+                                          vyi[k] - pj.w, vzi[k] - vzj, ri[k] + rj, cx, cy, cz, rinv);
+                    const bool valid = (j < N) & (j != ibase + k);   // all_diffs drops j == i (stateutils.py:41-49)
+                    gx[k] += valid ? cx : 0.0f;                       // select, so a NaN on the diagonal never leaks
+                    gy[k] += valid ? cy : 0.0f;
+                    if (Z3) gz[k] += valid ? cz : 0.0f;
+                    flag = fmaxf(flag, valid ? rinv : 0.0f);
                 }
             }
-            if (t + 1 < ntiles) {
-                s_pk[buf ^ 1][tid] = r_pk;
-                if (Z3) s_zv[buf ^ 1][tid] = r_zv;
-                if (RAD) s_rad[buf ^ 1][tid] = r_rad;
-            }
+        };
+
+        if (STAGED) {
+            const int ntiles = (N + TILE_J - 1) / TILE_J;
+            float4 r_pk = a.pk_cur[tid];
+            float2 r_zv = make_float2(0.f, 0.f);
+            float r_rad = 0.0f;
+            if (Z3) r_zv = a.zv_cur[tid];
+            if (RAD) r_rad = a.radius[tid];
+            s_pk[0][tid] = r_pk;
+            if (Z3) s_zv[0][tid] = r_zv;
+            if (RAD) s_rad[0][tid] = r_rad;
             __syncthreads();
+            for (int t = 0; t < ntiles; ++t) {
+                const int buf = t & 1;
+                if (t + 1 < ntiles) {                // prefetch the next tile while this one is consumed
+                    r_pk = a.pk_cur[(t + 1) * TILE_J + tid];
+                    if (Z3) r_zv = a.zv_cur[(t + 1) * TILE_J + tid];
+                    if (RAD) r_rad = a.radius[(t + 1) * TILE_J + tid];
+                }
+#pragma unroll 1
+                for (int s = 0; s < TILE_J / WAVE; ++s) {
+                    const int j0 = t * TILE_J + s * WAVE;                    // uniform
+                    if (j0 >= N) break;
+                    const float4 pj = s_pk[buf][s * WAVE + lane];
+                    float zj = 0.0f, vzj = 0.0f, rj = 0.0f;
+                    if (Z3) { const float2 zz = s_zv[buf][s * WAVE + lane]; zj = zz.x; vzj = zz.y; }
+                    if (RAD) rj = s_rad[buf][s * WAVE + lane];
+                    step(j0, pj, zj, vzj, rj);
+                }
+                if (t + 1 < ntiles) {
+                    s_pk[buf ^ 1][tid] = r_pk;
+                    if (Z3) s_zv[buf ^ 1][tid] = r_zv;
+                    if (RAD) s_rad[buf ^ 1][tid] = r_rad;
+                }
+                __syncthreads();
+            }
+        } else {
+            // TEAM 4: this wave streams records 64*(4s + wave) + lane, one step ahead in registers
+            int j0 = wave * WAVE;
+            float4 n_pk = make_float4(0.f, 0.f, 0.f, 0.f);
+            float2 n_zv = make_float2(0.f, 0.f);
+            float n_rad = 0.0f;
+            if (j0 < N) {
+                n_pk = a.pk_cur[j0 + lane];
+                if (Z3) n_zv = a.zv_cur[j0 + lane];
+                if (RAD) n_rad = a.radius[j0 + lane];
+            }
+#pragma unroll 1
+            for (; j0 < N; j0 += WAVE * TEAM) {
+                const float4 pj = n_pk;
+                const float2 zz = n_zv;
+                const float rj = n_rad;
+                const int jn = j0 + WAVE * TEAM;
+                if (jn < N) {                                         // rows up to N_pad are allocated
+                    n_pk = a.pk_cur[jn + lane];
+                    if (Z3) n_zv = a.zv_cur[jn + lane];
+                    if (RAD) n_rad = a.radius[jn + lane];
+                }
+                step(j0, pj, zz.x, zz.y, rj);
+            }
         }
         // 2-D fast path: a coincident valid pair needs the reference's zero-vector conventions -> redo this
-        // wave's rows with the exact body, straight from global memory (rare; no workgroup barrier inside).
+        // wave's part with the exact body, straight from global memory (rare; no workgroup barrier inside).
         if (!Z3) {
             flag = wave_max(flag);
             if (flag >= COINCIDENT_RINV) {
 #pragma unroll
                 for (int k = 0; k < IPW; ++k) { gx[k] = 0.0f; gy[k] = 0.0f; }
-                for (int j0 = 0; j0 < N; j0 += WAVE) {
+                for (int j0 = (TEAM == 1 ? 0 : wave * WAVE); j0 < N; j0 += WAVE * TEAM) {
                     const int j = j0 + lane;
                     const float4 pj = a.pk_cur[min(j, N - 1)];
                     const float rj = RAD ? a.radius[min(j, N - 1)] : 0.0f;
@@ -358,9 +421,24 @@ __global__ __launch_bounds__(BLOCK) void sfm_tick_kernel(const TickArgs a) {
         }
     }
 
+    if (TEAM > 1) {                                  // partial sums of the team meet in LDS, fixed order
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < IPW; ++k) { s_part[wave][k][0] = gx[k]; s_part[wave][k][1] = gy[k]; s_part[wave][k][2] = gz[k]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < IPW; ++k) {
+            gx[k] = ((s_part[0][k][0] + s_part[1][k][0]) + s_part[2][k][0]) + s_part[3][k][0];
+            gy[k] = ((s_part[0][k][1] + s_part[1][k][1]) + s_part[2][k][1]) + s_part[3][k][1];
+            gz[k] = ((s_part[0][k][2] + s_part[1][k][2]) + s_part[2][k][2]) + s_part[3][k][2];
+        }
+    }
+
     // ---- per-pedestrian part: geometry forces + epilogue (wave-uniform values, lane 0 stores) ----------
+    // TEAM 1: the wave walks its own rows; TEAM 4: row k is finished by wave k mod 4.
 #pragma unroll 1
-    for (int k = 0; k < IPW; ++k) {
+    for (int k = (TEAM == 1 ? 0 : wave); k < IPW; k += TEAM) {
         const int i = ibase + k;
         if (i >= a.i_end) break;
         // static indexing of the register arrays: pick row k with a chain of selects
@@ -442,6 +520,260 @@ __global__ __launch_bounds__(BLOCK) void sfm_tick_kernel(const TickArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// symmetric pedestrian force: every unordered pair once (F_ji = -F_ij), systolic over the wavefront
+// ------------------------------------------------------------------------------------------------------
+// Pedestrians are cut into tiles of 64.  A workgroup owns one unordered tile pair (ta, tb): each lane keeps
+// ONE pedestrian j of tile tb fixed in registers, while the 64 pedestrians i of tile ta -- together with
+// their force accumulators -- rotate through the lanes one step at a time (6 DPP wavefront-rotate moves per
+// 64 pairs).  Each step evaluates the Moussaid term once and adds it to the travelling F_i and subtracts it
+// from the resident F_j, so nothing is reduced across lanes and nothing is atomically added.  The 64 steps
+// of a tile pair are split over the 4 waves; partial sums meet in LDS in a fixed order and are written, one
+// coalesced 512-B row per side, to slab[partner tile][pedestrian] -- every slab entry is written exactly
+// once per tick, and the epilogue kernel sums a pedestrian's n_t entries in a fixed order (deterministic).
+// Padding rows are "ghost" pedestrians parked ~3e15 m away at distinct positions: their terms underflow to
+// exactly 0, so no masking is needed.  Planar crowds without use_ped_radius only; anything else, and
+// sharded runs, use the ordered kernel above.
+__device__ __forceinline__ float rot1(float v) {
+    const int b = __float_as_int(v);   // old == src: lets the register allocator rotate in place (no pre-clear move)
+    return __int_as_float(__builtin_amdgcn_update_dpp(b, b, 0x134 /* wave_rol:1 */, 0xf, 0xf, false));
+}
+
+__global__ void sfm_dpp_probe_kernel(int* out) {       // which way does wave_rol:1 move data?
+    const int lane = threadIdx.x & 63;
+    out[lane] = __builtin_amdgcn_update_dpp(0, lane, 0x134, 0xf, 0xf, false);
+}
+
+__global__ __launch_bounds__(BLOCK) void sfm_pair_sym_kernel(const float4* __restrict__ pk, const IxConst c,
+                                                             const SymArgs sa) {
+    __shared__ float2 s_fi[WAVES_PER_BLOCK][WAVE];
+    __shared__ float2 s_fj[WAVES_PER_BLOCK][WAVE];
+    const int tid = threadIdx.x;
+    const int lane = tid & (WAVE - 1);
+    const int wave = uniform(tid >> 6);
+    const int n_t = sa.n_t;
+    const int half_up = (n_t + 1) >> 1;
+    const int shift = blockIdx.y;                 // tile distance: 0 = diagonal blocks
+    const int bx = blockIdx.x;
+    int ta, tb, sig0, nsteps;
+    bool diag = false;
+    if (shift == 0) {
+        // diagonal tiles are half the work (32 steps): two of them share a workgroup, two waves each
+        if (bx >= half_up) return;
+        ta = (wave < 2) ? bx : bx + half_up;
+        if (ta >= n_t) { ta = -1; }
+        tb = ta;
+        diag = true;
+        sig0 = 1 + 16 * (wave & 1);               // sigma 1..16 / 17..32 (sigma = 32 is one-sided)
+        nsteps = 16;
+    } else {
+        if (!(n_t & 1) && shift == (n_t >> 1) && bx >= (n_t >> 1)) return;   // antipodal pairs appear twice
+        ta = bx;
+        tb = bx + shift;
+        if (tb >= n_t) tb -= n_t;
+        sig0 = 16 * wave;
+        nsteps = 16;
+    }
+    if (sa.debug_steps >= 0) nsteps = sa.debug_steps;
+
+    float fxi = 0.f, fyi = 0.f, fxj = 0.f, fyj = 0.f, flag = 0.f;
+    int i_end_loc = lane;
+    if (ta >= 0) {
+        const float4 pj = pk[tb * WAVE + lane];
+        const int i_loc0 = (lane + sa.dir * sig0) & (WAVE - 1);
+        const float4 pi0 = pk[ta * WAVE + i_loc0];
+        float xi = pi0.x, yi = pi0.y, vxi = pi0.z, vyi = pi0.w;
+        auto step = [&](bool both) {
+            float cx = 0.f, cy = 0.f, cz = 0.f, rinv;
+            moussaid<false, false, false>(c, pj.x - xi, pj.y - yi, 0.f, vxi - pj.z, vyi - pj.w, 0.f, 0.f, cx, cy, cz, rinv);
+            flag = fmaxf(flag, rinv);
+            fxi += cx;
+            fyi += cy;
+            if (both) { fxj -= cx; fyj -= cy; }
+            xi = rot1(xi); yi = rot1(yi); vxi = rot1(vxi); vyi = rot1(vyi);
+            fxi = rot1(fxi); fyi = rot1(fyi);
+        };
+        // sigma = 32 on a diagonal tile meets every unordered pair {l, l+32} in BOTH lanes: one-sided there
+        const bool tail_one_sided = diag && (sig0 + nsteps - 1 == 32);        // uniform
+        const int n_sym = tail_one_sided ? nsteps - 1 : nsteps;
+#pragma unroll 2
+        for (int s = 0; s < n_sym; ++s) step(true);
+        if (tail_one_sided) step(false);
+        i_end_loc = (lane + sa.dir * (sig0 + nsteps)) & (WAVE - 1);
+        flag = wave_max(flag);
+        if (flag >= COINCIDENT_RINV && lane == 0) { sa.tile_flag[ta] = 1; sa.tile_flag[tb] = 1; }
+    }
+    s_fi[wave][i_end_loc] = make_float2(fxi, fyi);
+    s_fj[wave][lane] = make_float2(fxj, fyj);
+    __syncthreads();
+    if (shift == 0) {
+        // waves 0,1 -> tile bx ; waves 2,3 -> tile bx + half_up
+        if (tid < 2 * WAVE) {
+            const int g = tid >> 6;                       // 0 or 1
+            const int t = (g == 0) ? bx : bx + half_up;
+            if (t < n_t) {
+                const int p = tid & (WAVE - 1);
+                const float2 a0 = s_fi[2 * g][p], a1 = s_fi[2 * g + 1][p], b0 = s_fj[2 * g][p], b1 = s_fj[2 * g + 1][p];
+                sa.slab[(size_t)t * sa.stride + t * WAVE + p] = make_float2(((a0.x + a1.x) + b0.x) + b1.x,
+                                                                            ((a0.y + a1.y) + b0.y) + b1.y);
+            }
+        }
+    } else if (tid < 2 * WAVE) {
+        const int p = tid & (WAVE - 1);
+        if (tid < WAVE) {     // force on tile ta's pedestrians from tile tb
+            const float2 a0 = s_fi[0][p], a1 = s_fi[1][p], a2 = s_fi[2][p], a3 = s_fi[3][p];
+            sa.slab[(size_t)tb * sa.stride + ta * WAVE + p] = make_float2(((a0.x + a1.x) + a2.x) + a3.x, ((a0.y + a1.y) + a2.y) + a3.y);
+        } else {              // force on tile tb's pedestrians from tile ta
+            const float2 a0 = s_fj[0][p], a1 = s_fj[1][p], a2 = s_fj[2][p], a3 = s_fj[3][p];
+            sa.slab[(size_t)ta * sa.stride + tb * WAVE + p] = make_float2(((a0.x + a1.x) + a2.x) + a3.x, ((a0.y + a1.y) + a2.y) + a3.y);
+        }
+    }
+}
+
+// Epilogue of the symmetric path: one workgroup of 16 waves per tile of 64 pedestrians.  The waves split the
+// partner tiles of the slab column sum (all loads of a wave in flight at once, combined in LDS in a fixed
+// order), run the geometry forces (a wave per pedestrian, as in the ordered kernel), and wave 0 integrates
+// the 64 pedestrians lane-parallel with coalesced stores.  Latency-bound by design: few, short chains.
+constexpr int EPI_WAVES = 16;
+constexpr int EPI_BLOCK = EPI_WAVES * WAVE;
+
+template <bool RAD>
+__global__ __launch_bounds__(EPI_BLOCK) void sfm_sym_epilogue_kernel(const TickArgs a, const SymArgs sa) {
+    __shared__ float2 s_sum[EPI_WAVES][WAVE];
+    __shared__ float s_geo[WAVE][6];
+    __shared__ float2 s_exact[WAVE];
+    const int tid = threadIdx.x;
+    const int lane = tid & (WAVE - 1);
+    const int wave = uniform(tid >> 6);
+    const int t = blockIdx.x;
+    const int N = a.N;
+    const int i = t * WAVE + lane;
+
+    // own state first: independent of the slab, so its latency overlaps the column sum
+    float4 st = make_float4(0.f, 0.f, 0.f, 0.f), o = st;
+    uint32_t nd0 = 0;
+    if (wave == 0 && i < N) { st = a.pk_cur[i]; o = a.own[i]; if (a.flags & 2u) nd0 = a.draws[i]; }
+
+    // 1. slab column sums: wave w takes partner tiles w, w+16, ...
+    float2 acc = make_float2(0.f, 0.f);
+    if (a.en_ped) {
+        const float2* col = sa.slab + i;
+        int u = wave;
+        for (; u + 3 * EPI_WAVES < sa.n_t; u += 4 * EPI_WAVES) {          // 4 independent loads in flight
+            const float2 v0 = col[(size_t)u * sa.stride], v1 = col[(size_t)(u + EPI_WAVES) * sa.stride];
+            const float2 v2 = col[(size_t)(u + 2 * EPI_WAVES) * sa.stride], v3 = col[(size_t)(u + 3 * EPI_WAVES) * sa.stride];
+            acc.x += (v0.x + v1.x) + (v2.x + v3.x);
+            acc.y += (v0.y + v1.y) + (v2.y + v3.y);
+        }
+        for (; u < sa.n_t; u += EPI_WAVES) {
+            const float2 v = col[(size_t)u * sa.stride];
+            acc.x += v.x;
+            acc.y += v.y;
+        }
+    }
+    s_sum[wave][lane] = acc;
+    for (int p = tid; p < WAVE * 6; p += EPI_BLOCK) (&s_geo[0][0])[p] = 0.0f;
+    const bool exact = a.en_ped && (sa.tile_flag[t] != 0);       // uniform per workgroup
+    __syncthreads();
+
+    // 2. coincident pairs in this tile: recompute its rows with the exact ordered body (rare)
+    if (exact) {
+        for (int p = wave; p < WAVE; p += EPI_WAVES) {
+            const int ip = t * WAVE + p;
+            if (ip >= N) break;
+            const float4 si = a.pk_cur[ip];
+            const float xi = uniform(si.x), yi = uniform(si.y), vxi = uniform(si.z), vyi = uniform(si.w);
+            float gx = 0.f, gy = 0.f;
+            for (int j0 = 0; j0 < N; j0 += WAVE) {
+                const int j = j0 + lane;
+                const float4 pj = a.pk_cur[min(j, N - 1)];
+                float cx = 0.f, cy = 0.f, cz = 0.f, rinv;
+                moussaid<false, false, true>(a.ped, pj.x - xi, pj.y - yi, 0.f, vxi - pj.z, vyi - pj.w, 0.f, 0.f, cx, cy, cz, rinv);
+                const bool valid = (j < N) & (j != ip);
+                gx += valid ? cx : 0.f;
+                gy += valid ? cy : 0.f;
+            }
+            gx = wave_sum(gx);
+            gy = wave_sum(gy);
+            if (lane == 0) s_exact[p] = make_float2(gx, gy);
+        }
+    }
+    // 3. geometry forces, a wave per pedestrian
+    const bool any_geo = (a.en_border && a.borders.K > 0) || (a.en_static && a.statics.K > 0) || (a.en_dynamic && a.dynamics.K > 0);
+    if (any_geo) {
+        for (int p = wave; p < WAVE; p += EPI_WAVES) {
+            const int ip = t * WAVE + p;
+            if (ip >= N) break;
+            const float4 si = a.pk_cur[ip];
+            const float x = uniform(si.x), y = uniform(si.y), vx = uniform(si.z), vy = uniform(si.w);
+            const float r = uniform(a.own[ip].w);
+            float fbx = 0.f, fby = 0.f, fsx = 0.f, fsy = 0.f, fdx = 0.f, fdy = 0.f;
+            if (a.en_border && a.borders.K > 0 && !(a.crossing && a.crossing[ip]))
+                border_force<RAD>(a, x, y, r, lane, fbx, fby);
+            if (a.en_static && a.statics.K > 0)
+                obstacle_force<RAD>(a.statics, a.stat, false, x, y, vx, vy, r, lane, fsx, fsy);
+            if (a.en_dynamic && a.dynamics.K > 0)
+                obstacle_force<RAD>(a.dynamics, a.dyn, true, x, y, vx, vy, r, lane, fdx, fdy);
+            if (lane == 0) {
+                s_geo[p][0] = fbx; s_geo[p][1] = fby; s_geo[p][2] = fsx; s_geo[p][3] = fsy; s_geo[p][4] = fdx; s_geo[p][5] = fdy;
+            }
+        }
+    }
+    if (exact || any_geo) __syncthreads();
+    if (wave != 0) return;
+    if (exact && lane == 0) sa.tile_flag[t] = 0;      // re-armed for the next tick
+    if (i >= N) return;
+
+    // 4. lane-parallel epilogue for the 64 pedestrians of the tile
+    float2 g = s_sum[0][lane];
+#pragma unroll
+    for (int w = 1; w < EPI_WAVES; ++w) { const float2 b = s_sum[w][lane]; g.x += b.x; g.y += b.y; }
+    if (exact) g = s_exact[lane];
+    const float fpx = a.en_ped ? a.ped.negA * g.x : 0.f, fpy = a.en_ped ? a.ped.negA * g.y : 0.f;
+    const float fbx = s_geo[lane][0], fby = s_geo[lane][1], fsx = s_geo[lane][2], fsy = s_geo[lane][3];
+    const float fdx = s_geo[lane][4], fdy = s_geo[lane][5];
+    const float x = st.x, y = st.y, vx = st.z, vy = st.w, ts = o.z;
+    float wx = o.x, wy = o.y;
+    float fax = 0.f, fay = 0.f;
+    if (a.en_acc) {
+        const float tx_ = wx - x, ty_ = wy - y;
+        const float nrm = sqrtf(fmaf(tx_, tx_, ty_ * ty_));
+        const float inv = (nrm == 0.0f) ? 1.0f : 1.0f / nrm;
+        fax = (ts * (tx_ * inv) - vx) * a.inv_tau;
+        fay = (ts * (ty_ * inv) - vy) * a.inv_tau;
+    }
+    const float Fx = (((fax + fpx) + fbx) + fsx) + fdx;
+    const float Fy = (((fay + fpy) + fby) + fsy) + fdy;
+    float nvx = fmaf(a.dt, Fx, vx), nvy = fmaf(a.dt, Fy, vy);
+    float sp = sqrtf(fmaf(nvx, nvx, nvy * nvy));
+    sp = (sp == 0.0f) ? 1.0f : sp;
+    const float fac = fminf(1.0f, (ts * a.max_speed_factor) / sp);
+    nvx *= fac; nvy *= fac;
+    if (a.flags & 2u) {
+        const float ax_ = wx - x, ay_ = wy - y;
+        if (fmaf(ax_, ax_, ay_ * ay_) < a.arrive_thr2) {
+            const uint32_t nd = nd0 + 1u;
+            wx = waypoint_coord(a.seed, (uint32_t)i, nd, 0u, a.world_side);
+            wy = waypoint_coord(a.seed, (uint32_t)i, nd, 1u, a.world_side);
+            a.own[i] = make_float4(wx, wy, o.z, o.w);
+            a.draws[i] = nd;
+        }
+    }
+    float nx = x, ny = y;
+    if (a.flags & 1u) { nx = fmaf(a.dt, nvx, x); ny = fmaf(a.dt, nvy, y); }
+    a.pk_next[i] = make_float4(nx, ny, nvx, nvy);
+    if (a.rec) {
+        float* rc = a.rec;
+        const size_t n = (size_t)N;
+        rc[(0 * 3 + 0) * n + i] = fax; rc[(0 * 3 + 1) * n + i] = fay; rc[(0 * 3 + 2) * n + i] = 0.f;
+        rc[(1 * 3 + 0) * n + i] = fpx; rc[(1 * 3 + 1) * n + i] = fpy; rc[(1 * 3 + 2) * n + i] = 0.f;
+        rc[(2 * 3 + 0) * n + i] = fbx; rc[(2 * 3 + 1) * n + i] = fby; rc[(2 * 3 + 2) * n + i] = 0.f;
+        rc[(3 * 3 + 0) * n + i] = fsx; rc[(3 * 3 + 1) * n + i] = fsy; rc[(3 * 3 + 2) * n + i] = 0.f;
+        rc[(4 * 3 + 0) * n + i] = fdx; rc[(4 * 3 + 1) * n + i] = fdy; rc[(4 * 3 + 2) * n + i] = 0.f;
+        rc[(5 * 3 + 0) * n + i] = Fx;  rc[(5 * 3 + 1) * n + i] = Fy;  rc[(5 * 3 + 2) * n + i] = 0.f;
+    }
+}
+
 // get_arrived_peds (pedestrian_simulation.py:88-97) on the current device state.
 __global__ void sfm_arrived_kernel(const float4* __restrict__ pk, const float4* __restrict__ own, int N, float thr2,
                                    uint8_t* __restrict__ mask) {
@@ -456,29 +788,59 @@ __global__ void sfm_arrived_kernel(const float4* __restrict__ pk, const float4* 
 // ------------------------------------------------------------------------------------------------------
 // launch helpers (host)
 // ------------------------------------------------------------------------------------------------------
-template <int IPW, bool Z3, bool RAD>
+template <int IPW, bool Z3, bool RAD, int TEAM>
 static hipError_t launch_one(const TickArgs& a, hipStream_t st) {
     const int n_local = a.i_end - a.i_begin;
     if (n_local <= 0) return hipSuccess;
-    const int per_block = IPW * WAVES_PER_BLOCK;
+    const int per_block = IPW * (WAVES_PER_BLOCK / TEAM);
     const int grid = (n_local + per_block - 1) / per_block;
-    hipLaunchKernelGGL((sfm_tick_kernel<IPW, Z3, RAD>), dim3(grid), dim3(BLOCK), 0, st, a);
+    hipLaunchKernelGGL((sfm_tick_kernel<IPW, Z3, RAD, TEAM>), dim3(grid), dim3(BLOCK), 0, st, a);
     return hipGetLastError();
 }
 
-template <bool Z3, bool RAD>
+template <bool Z3, bool RAD, int TEAM>
 static hipError_t launch_ipw(int ipw, const TickArgs& a, hipStream_t st) {
     switch (ipw) {
-        case 1: return launch_one<1, Z3, RAD>(a, st);
-        case 2: return launch_one<2, Z3, RAD>(a, st);
-        case 4: return launch_one<4, Z3, RAD>(a, st);
-        default: return launch_one<8, Z3, RAD>(a, st);
+        case 1: return launch_one<1, Z3, RAD, TEAM>(a, st);
+        case 2: return launch_one<2, Z3, RAD, TEAM>(a, st);
+        case 4: return launch_one<4, Z3, RAD, TEAM>(a, st);
+        default: return launch_one<8, Z3, RAD, TEAM>(a, st);
     }
 }
 
-hipError_t launch_tick(int ipw, bool z3, bool rad, const TickArgs& a, hipStream_t st) {
-    if (z3) return rad ? launch_ipw<true, true>(ipw, a, st) : launch_ipw<true, false>(ipw, a, st);
-    return rad ? launch_ipw<false, true>(ipw, a, st) : launch_ipw<false, false>(ipw, a, st);
+template <int TEAM>
+static hipError_t launch_team(int ipw, bool z3, bool rad, const TickArgs& a, hipStream_t st) {
+    if (z3) return rad ? launch_ipw<true, true, TEAM>(ipw, a, st) : launch_ipw<true, false, TEAM>(ipw, a, st);
+    return rad ? launch_ipw<false, true, TEAM>(ipw, a, st) : launch_ipw<false, false, TEAM>(ipw, a, st);
+}
+
+hipError_t launch_tick(int ipw, int team, bool z3, bool rad, const TickArgs& a, hipStream_t st) {
+    return team == 4 ? launch_team<4>(ipw, z3, rad, a, st) : launch_team<1>(ipw, z3, rad, a, st);
+}
+
+hipError_t launch_sym_tick(const TickArgs& a, const SymArgs& sa, hipStream_t st) {
+    if (a.N <= 0) return hipSuccess;
+    if (a.en_ped && a.N > 1) {
+        hipLaunchKernelGGL(sfm_pair_sym_kernel, dim3(sa.n_t, sa.n_t / 2 + 1), dim3(BLOCK), 0, st, a.pk_cur, a.ped, sa);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((sfm_sym_epilogue_kernel<false>), dim3(sa.n_t), dim3(EPI_BLOCK), 0, st, a, sa);
+    return hipGetLastError();
+}
+
+// +1 if wave_rol:1 makes lane l receive lane l+1's value, -1 if lane l-1's, 0 on failure
+int probe_dpp_direction(hipStream_t st) {
+    int* d = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&d), 64 * sizeof(int)) != hipSuccess) return 0;
+    hipLaunchKernelGGL(sfm_dpp_probe_kernel, dim3(1), dim3(64), 0, st, d);
+    int h[64];
+    hipError_t e = hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+    hipFree(d);
+    if (e != hipSuccess) return 0;
+    bool up = true, down = true;
+    for (int l = 0; l < 64; ++l) { up &= (h[l] == ((l + 1) & 63)); down &= (h[l] == ((l + 63) & 63)); }
+    return up ? 1 : (down ? -1 : 0);
 }
 
 hipError_t launch_arrived(const float4* pk, const float4* own, int N, float thr2, uint8_t* mask, hipStream_t st) {

@@ -1,0 +1,145 @@
+"""GPU tests of the drop-in boundary: the PedestrianSimulation / Force facade driven the way
+run_simulation.py drives the reference (spawn tuples, update_dynamic_obstacles, tick, get_new_velocities,
+get_arrived_peds, update_next_waypoint), checked against the reference's golden outputs."""
+import numpy as np
+import pytest
+
+import _golden_io as gio
+import _parity as P
+from carla_social_force_model_amd import forces as hip_forces
+from carla_social_force_model_amd.ped_mode_manager import PedMode, PedModeManager
+from carla_social_force_model_amd.pedestrian_simulation import PedestrianSimulation
+from oracle import sfm_oracle as O
+
+pytestmark = pytest.mark.gpu
+CASES = {p.split("/")[-1][:-4]: p for p in gio.list_cases()}
+
+
+def _mode_manager(name, speed, m):
+    mm = PedModeManager(name, float(speed), PedMode.WALKING_SIDEWALK, 1.5, 1.5)
+    steps = {0: [PedMode.IDLE], 2: [PedMode.CROSSING_ROAD] * 2, 3: [PedMode.CROSSING_ROAD] * 2 + [PedMode.WALKING_SIDEWALK],
+             4: [PedMode.CROSSING_ROAD]}.get(int(m), [])
+    for s in steps:
+        mm.set_mode(s)
+    assert int(mm.current_mode) == int(m)
+    return mm
+
+
+def _build(c):
+    info = [[c.border_centers[k], float(c.border_lengths[k])] for k in range(len(c.borders))]
+    sim = PedestrianSimulation(c.borders, info, c.static_obstacles, c.cfg, c.dt)
+    for i in range(c.n):
+        name = f"ped_{i}"
+        sim.spawn_pedestrian((name, 100 + i, c.loc[i], c.vel[i], c.waypoint[i],
+                              _mode_manager(name, c.target_speed[i], c.mode[i]), float(c.radius[i]), float(c.target_speed[i])))
+    if len(c.dynamic_obstacles):
+        m = len(c.dynamic_obstacles)
+        sim.update_dynamic_obstacles((list(range(m)), [o[0] for o in c.dynamic_obstacles], [0.0] * m,
+                                      [v for v in c.dynamic_vel], [np.array([2.4, 1.0])] * m,
+                                      [o[1] for o in c.dynamic_obstacles]))
+    return sim
+
+
+def _diag(c):
+    prm = O.OracleParams.from_config(c.cfg)
+    geom = O.Geometry(c.borders, c.border_centers, c.border_lengths, c.static_obstacles, c.dynamic_obstacles, c.dynamic_vel)
+    d = {}
+    with np.errstate(all="ignore"):
+        O.tick_forces(c.loc, c.vel, c.waypoint, c.z["mode_target_speed"], c.radius, c.crossing, geom, prm,
+                      theta_tol=P.THETA_TOL, tie_rel=P.TIE_REL, diag=d)
+    return d
+
+
+@pytest.mark.parametrize("name", ["c1_n64", "modes_n32", "all_s1_n256", "zspread_n64", "radius_n64", "single_ped"])
+def test_tick_through_facade(name):
+    c = gio.Case(CASES[name])
+    sim = _build(c)
+    try:
+        assert sim.get_new_velocities() is None
+        # per-force view of the fused engine (Force.get_force contract), on the untouched spawn state
+        sim.peds.apply_current_mode()
+        d = _diag(c)
+        for fname, f in sim.forces.items():
+            P.check_force(fname, f.get_force(sim.peds), c.ref(fname), d[fname][1], d[fname][0])
+        sim.tick(0.0)
+        nv = sim.get_new_velocities()
+        assert nv.dtype.names == ('id', 'vel') and nv['vel'].shape == (c.n, 3)
+        assert np.shares_memory(nv, sim.peds.state)                       # the reference's view semantics
+        assert np.array_equal(sim.peds.vel(), nv['vel'])
+        P.check_velocity(nv['vel'], c.ref("new_vel"), _diag(c)["total"][0], c.dt)
+        assert np.array_equal(sim.peds.target_speed(), c.z["mode_target_speed"])
+        assert list(sim.get_arrived_peds(2.0)) == [f"ped_{i}" for i in np.nonzero(c.ref("arrived"))[0]]
+        assert 0.0 in sim.get_states() and sim.get_states()[0.0]['mode'][0] == int(c.mode[0])
+    finally:
+        sim.close()
+
+
+def test_empty_simulation_and_despawn():
+    c = gio.Case(CASES["all_s0_n16"])
+    info = [[c.border_centers[k], float(c.border_lengths[k])] for k in range(len(c.borders))]
+    sim = PedestrianSimulation(c.borders, info, c.static_obstacles, c.cfg, c.dt)
+    try:
+        sim.tick(0.0)                                                      # no pedestrians: no-op (:60-61)
+        assert sim.get_new_velocities() is None and sim.get_arrived_peds(2.0) == []
+        for i in range(3):
+            sim.spawn_pedestrian((f"ped_{i}", i, c.loc[i], c.vel[i], c.waypoint[i],
+                                  _mode_manager(f"ped_{i}", 1.2, 1), 0.3, 1.2))
+        sim.tick(0.05)
+        sim.destroy_pedestrian("ped_1")
+        sim.tick(0.10)
+        assert sim.peds.size() == 2 and list(sim.peds.name()) == ["ped_0", "ped_2"]
+        assert np.isfinite(sim.get_new_velocities()['vel']).all()
+        for i in (0, 2):
+            sim.destroy_pedestrian(f"ped_{i}")
+        sim.tick(0.15)                                                     # empty again
+    finally:
+        sim.close()
+
+
+def test_standalone_force_classes_match_golden():
+    """forces.AccelerationForce / PedestrianForce / BorderForce / ObstacleForce slotted in one by one."""
+    c = gio.Case(CASES["c1_n64"])
+    sim = _build(c)                                                        # only used as a PedState factory here
+    sim.peds.apply_current_mode()
+    d = _diag(c)
+    info = [[c.border_centers[k], float(c.border_lengths[k])] for k in range(len(c.borders))]
+    fs = {"acceleration_force": hip_forces.AccelerationForce(c.dt, c.cfg),
+          "pedestrian_force": hip_forces.PedestrianForce(c.dt, c.cfg),
+          "border_force": hip_forces.BorderForce(c.dt, c.cfg, c.borders, info),
+          "static_obstacle_force": hip_forces.ObstacleForce(c.dt, c.cfg),
+          "dynamic_obstacle_force": hip_forces.ObstacleForce(c.dt, c.cfg, True)}
+    try:
+        assert np.array_equal(fs["dynamic_obstacle_force"].get_force(sim.peds), np.zeros((c.n, 3)))   # before any update
+        fs["static_obstacle_force"].update_obstacles(c.static_obstacles)
+        fs["dynamic_obstacle_force"].update_obstacles(c.dynamic_obstacles)
+        fs["dynamic_obstacle_force"].update_obstacle_velocities(c.dynamic_vel)
+        for name, f in fs.items():
+            got = f.get_force(sim.peds, debug=True)
+            assert got.shape == (c.n, 3) and got.dtype == np.float64
+            P.check_force(name, got, c.ref(name), d[name][1], d[name][0])
+    finally:
+        for f in fs.values():
+            f.close()
+        sim.close()
+
+
+def test_host_loop_trajectory_tracks_reference():
+    """20 ticks of the CARLA-free host loop through the facade (tick -> arrival -> waypoint swap -> move)
+    against the reference trajectory; fp32 forces vs float64, so a small, growth-aware bound."""
+    c = gio.Case(CASES["all_s2_n64"])
+    sim = _build(c)
+    queue, used = c.z["wp_queue"], np.zeros(c.n, dtype=int)
+    try:
+        sim.record_states = False
+        for k in range(c.ref("traj_loc").shape[0]):
+            sim.tick(k * c.dt)
+            for name in sim.get_arrived_peds(2.0):
+                i = int(name.split("_")[1])
+                used[i] += 1
+                wp = np.array([*queue[i, (used[i] - 1) % queue.shape[1]], 0.0])
+                sim.peds.update_next_waypoint(name, (wp, False))
+            sim.peds.state['loc'] = sim.peds.state['loc'] + c.dt * sim.peds.state['vel']
+            err = np.max(np.linalg.norm(sim.peds.loc() - c.ref("traj_loc")[k], axis=1))
+            assert err <= 2e-5 * (k + 1), f"tick {k}: {err:.2e}"
+    finally:
+        sim.close()

@@ -67,11 +67,14 @@ def test_arrived_matches_reference():
         assert np.array_equal(got[sure], c.ref("arrived")[sure]), c.name
 
 
+@pytest.mark.parametrize("team", [1, 4])
 @pytest.mark.parametrize("ipw", [1, 2, 4, 8])
 @pytest.mark.parametrize("n", [257, 1024, 3000])
-def test_pair_kernel_variants_vs_oracle(n, ipw, monkeypatch):
-    """All rows-per-wave variants of the pair kernel, ragged N (tail masking), against the C oracle."""
+def test_pair_kernel_variants_vs_oracle(n, ipw, team, monkeypatch):
+    """All rows-per-wave x team variants of the pair kernel, ragged N (tail masking), against the C oracle."""
     monkeypatch.setenv("SFM_IPW", str(ipw))
+    monkeypatch.setenv("SFM_TEAM", str(team))
+    monkeypatch.setenv("SFM_SYM", "0")            # the ordered kernel (what sharded runs use)
     sc = scenarios.make_scenario(n, 900 + n)
     cfg = default_sfm_config(("acceleration_force", "pedestrian_force"))
     prm = O.OracleParams.from_config(cfg)
@@ -81,9 +84,68 @@ def test_pair_kernel_variants_vs_oracle(n, ipw, monkeypatch):
     try:
         eng.upload_state(sc.loc, sc.vel, sc.waypoint, sc.target_speed, sc.radius, None)
         eng.tick(record=True)
-        assert f"<{ipw}," in eng.kernel_variant()
+        assert f"<{ipw}," in eng.kernel_variant() and eng.kernel_variant().endswith(f",{team}>")
         P.check_force("total", eng.forces("total"), total, absum, expo)
         P.check_velocity(eng.velocities(), v_new, expo, 0.05)
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("n", [64, 65, 257, 1000, 1024, 3000, 4160])
+def test_symmetric_path_vs_oracle(n, monkeypatch):
+    """The symmetric tile-pair kernel (every unordered pair once) + epilogue kernel: ragged N, odd and even
+    tile counts, single tile, against the C oracle -- and bit-identical from run to run (no atomics)."""
+    monkeypatch.setenv("SFM_SYM", "1")
+    sc = scenarios.make_scenario(n, 1300 + n, n_borders=6, n_static=4, border_len=(5.0, 20.0))
+    cfg = default_sfm_config(("acceleration_force", "pedestrian_force", "border_force", "static_obstacle_force"))
+    prm = O.OracleParams.from_config(cfg)
+    geom = O.Geometry(sc.borders, sc.border_centers, sc.border_lengths, sc.static_obstacles, [], None)
+    per, total, v_new, expo, absum = c_oracle.tick(sc.loc, sc.vel, sc.waypoint, sc.target_speed, sc.radius,
+                                                   np.zeros(n, bool), geom, prm, 0.05, theta_tol=P.THETA_TOL)
+    eng = SfmEngine(cfg, 0.05)
+    try:
+        eng.set_borders(sc.borders, sc.border_centers, sc.border_lengths)
+        eng.set_static_obstacles(sc.static_obstacles)
+        runs = []
+        for _ in range(2):
+            eng.upload_state(sc.loc, sc.vel, sc.waypoint, sc.target_speed, sc.radius, None)
+            eng.tick(record=True)
+            assert "sym" in eng.kernel_variant()
+            runs.append((eng.forces("total"), eng.velocities()))
+        assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1])
+        P.check_force("pedestrian", eng.forces("pedestrian_force"), per["pedestrian_force"], absum, expo)
+        P.check_force("total", runs[0][0], total, absum, expo)
+        P.check_velocity(runs[0][1], v_new, expo, 0.05)
+    finally:
+        eng.close()
+
+
+def test_symmetric_path_coincident_pairs(monkeypatch):
+    """Coincident pedestrians inside the symmetric path: the tile flag routes their tiles through the exact
+    body, reproducing the reference's NaN (equal velocities) and finite (different velocities) results."""
+    monkeypatch.setenv("SFM_SYM", "1")
+    n = 300
+    sc = scenarios.make_scenario(n, 99)
+    sc.loc[70] = sc.loc[3]; sc.vel[70] = sc.vel[3]            # NaN pair, different tiles
+    sc.loc[200] = sc.loc[201]                                  # finite coincident pair, same tile
+    cfg = default_sfm_config(("acceleration_force", "pedestrian_force"))
+    prm = O.OracleParams.from_config(cfg)
+    with np.errstate(all="ignore"):
+        per, total, v_new, expo, absum = c_oracle.tick(sc.loc, sc.vel, sc.waypoint, sc.target_speed, sc.radius,
+                                                       np.zeros(n, bool), O.Geometry(), prm, 0.05, theta_tol=P.THETA_TOL)
+    assert np.isnan(total[3]).any() and np.isnan(total[70]).any() and np.isfinite(total[200]).all()
+    eng = SfmEngine(cfg, 0.05)
+    try:
+        for _ in range(2):          # second tick-from-same-state checks the flags were re-armed
+            eng.upload_state(sc.loc, sc.vel, sc.waypoint, sc.target_speed, sc.radius, None)
+            eng.tick(record=True)
+            assert "sym" in eng.kernel_variant()
+            P.check_force("total", eng.forces("total"), total, absum, expo)
+        # the flags are consumed: a clean crowd afterwards is clean
+        sc2 = scenarios.make_scenario(n, 100)
+        eng.upload_state(sc2.loc, sc2.vel, sc2.waypoint, sc2.target_speed, sc2.radius, None)
+        eng.tick(record=True)
+        assert np.isfinite(eng.forces("total")).all()
     finally:
         eng.close()
 

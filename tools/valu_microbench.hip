@@ -4,7 +4,8 @@
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 typedef float float2v __attribute__((ext_vector_type(2)));
 template <int OP>
-__global__ void k(float* out, int iters, float seed) {
+__global__ void k(float* out, int iters, float seed, unsigned long long* stamps) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     float a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
     float2v p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7}, p4 = {a1, a3}, p5 = {a0, a2}, p6 = {a5, a7}, p7 = {a4, a6};
     const float c = 1.0001f, d = 0.5f;
@@ -34,29 +35,34 @@ __global__ void k(float* out, int iters, float seed) {
             a4 = fmaf(a4, c, d); a5 = __builtin_amdgcn_exp2f(a5); a6 = fmaf(a6, c, d); a7 = __builtin_amdgcn_exp2f(a7);
         }
     }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (blockIdx.x == 0 && threadIdx.x == 0) { stamps[0] = t1 - t0; stamps[1] = r1 - r0; }
     out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y + p4.x + p4.y + p5.x + p5.y + p6.x + p6.y + p7.x + p7.y;
 }
 template <int OP>
 int run(const char* name, int waves_per_simd, float lanes_per_inst) {
     const int blocks = 256 * waves_per_simd;  // 256 threads = 4 waves -> one wave per SIMD per block per CU
     float* out; CHECK(hipMalloc(&out, sizeof(float) * blocks * 256));
-    const int iters = 20000;
+    const int iters = 400000;
+    unsigned long long* stamps; CHECK(hipMalloc(&stamps, 16));
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-    hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, out, 100, 0.001f);
+    hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, out, 100, 0.001f, stamps);
     CHECK(hipDeviceSynchronize());
     CHECK(hipEventRecord(e0));
-    hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, out, iters, 0.001f);
+    hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, out, iters, 0.001f, stamps);
     CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
     float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+    unsigned long long hs[2]; CHECK(hipMemcpy(hs, stamps, 16, hipMemcpyDeviceToHost));
+    const double ghz = (double)hs[0] / (double)hs[1] * 0.1;   // s_memtime ticks per 100 MHz realtime tick
     const double insts_per_simd = (double)iters * 8 * waves_per_simd;   // wave-instructions issued on one SIMD
-    const double cyc = ms * 1e-3 * 2.4e9;
-    printf("%-14s waves/SIMD=%d  %.3f ms  %.2f cycles(@2.4GHz)/wave-inst  -> %.1f lane-ops/clk/SIMD\n", name, waves_per_simd, ms,
+    const double cyc = ms * 1e-3 * ghz * 1e9;
+    printf("%-14s waves/SIMD=%d  %.3f ms  clock %.2f GHz  %.2f cycles/wave-inst  -> %.1f lane-ops/clk/SIMD\n", name, waves_per_simd, ms, ghz,
            cyc / insts_per_simd, 64.0 * lanes_per_inst * insts_per_simd / cyc);
     CHECK(hipFree(out));
     return 0;
 }
 int main() {
-    for (int w : {1, 2, 4, 8}) {
+    for (int w : {4, 8}) {
         run<0>("v_fma_f32", w, 1); run<1>("v_pk_fma_f32", w, 2); run<4>("v_pk_mul_f32", w, 2); run<2>("v_exp_f32", w, 1);
         run<3>("v_rsq_f32", w, 1); run<5>("cmp+cndmask", w, 1); run<6>("fma+exp mix", w, 1);
     }
