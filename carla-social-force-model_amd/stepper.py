@@ -101,9 +101,10 @@ class ShardedStepper:
         engine.set_shard(self.lo, self.hi)
         self.ticks_done = 0
 
-    def exchange(self):
-        """The one collective of a tick: in-place all-gather of the packed records."""
-        if self.world == 1:
+    def exchange(self, force=False):
+        """The one collective of a tick: in-place all-gather of the packed records.  ``force`` issues it on a
+        single-rank group too (used to exercise the RCCL path on a one-GPU box)."""
+        if self.world == 1 and not force:
             return
         import torch.distributed as dist
         for buf, width in self.engine.packed():
@@ -127,7 +128,6 @@ class ShardedStepper:
         loc, vel, wp = self.engine.state()
         if self.world == 1:
             return loc, vel, wp
-        import torch
         import torch.distributed as dist
         mine = np.concatenate([loc[self.lo:self.hi], vel[self.lo:self.hi], wp[self.lo:self.hi]], axis=1)
         parts = [None] * self.world
