@@ -57,6 +57,8 @@ SYMBOLS = {
     "sfm_set_borders": (C.c_int, [_H, C.c_int, _I, _F, _F, _F, _F, _F]),
     "sfm_set_static_obstacles": (C.c_int, [_H, C.c_int, _I, _F, _F, _F, _F]),
     "sfm_set_dynamic_obstacles": (C.c_int, [_H, C.c_int, _I, _F, _F, _F, _F, _F, _F]),
+    "sfm_set_dynamic_boxes": (C.c_int, [_H, C.c_int, _I, _F, _F, _F, _F, _F, _F, _F, _F]),
+    "sfm_download_dynamic_obstacles": (C.c_int, [_H, _F, _F, _F, _F]),
     "sfm_upload_state": (C.c_int, [_H, C.c_int, _F, _F, _F, _F, _F, _F, _F, _F, _F, _F, _U8]),
     "sfm_set_shard": (C.c_int, [_H, C.c_int, C.c_int]),
     "sfm_set_waypoint_stream": (C.c_int, [_H, C.c_uint32, C.c_float, C.c_float]),

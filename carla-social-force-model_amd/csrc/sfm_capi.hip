@@ -17,6 +17,8 @@ hipError_t launch_tick(int ipw, int team, bool z3, bool rad, const TickArgs& a, 
 hipError_t launch_arrived(const float4* pk, const float4* own, int N, float thr2, uint8_t* mask, hipStream_t st);
 hipError_t launch_sym_tick(const TickArgs& a, const SymArgs& sa, hipStream_t st);
 int probe_dpp_direction(hipStream_t st);
+hipError_t launch_dynamic_boxes(float4* ctr, const int* off, const float2* local, const float2* rot, float2* pts, int M,
+                                float dt, int advance, hipStream_t st);
 }  // namespace sfm
 
 using namespace sfm;
@@ -51,6 +53,9 @@ struct SfmHandle {
     float* rec = nullptr;                 // [6][3][N]
     bool rec_valid = false;
     DevGeo borders, statics, dynamics;
+    float2* dyn_local = nullptr;          // device-side vehicles: ring-local offsets [P] and {cos,sin} yaw [M]
+    float2* dyn_rot = nullptr;
+    bool dyn_boxes = false;
 
     // symmetric pedestrian-force path (single shard, planar, no radius)
     float2* slab = nullptr;
@@ -174,6 +179,8 @@ int sfm_destroy(SfmHandle* h) {
     if (h->arrived) hipFree(h->arrived);
     if (h->draws) hipFree(h->draws);
     if (h->rec) hipFree(h->rec);
+    if (h->dyn_local) hipFree(h->dyn_local);
+    if (h->dyn_rot) hipFree(h->dyn_rot);
     if (h->slab) hipFree(h->slab);
     if (h->tile_flag) hipFree(h->tile_flag);
     free_geo(h->borders); free_geo(h->statics); free_geo(h->dynamics);
@@ -250,7 +257,46 @@ int sfm_set_dynamic_obstacles(SfmHandle* h, int M, const int32_t* offsets, const
     std::vector<float4> c4((size_t)(M > 0 ? M : 0));
     for (int k = 0; k < M; ++k)       // velocities default to 0 like ObstacleForce (forces.py:212-213)
         c4[k] = make_float4(cx[k], cy[k], vx ? vx[k] : 0.f, vy ? vy[k] : 0.f);
+    h->dyn_boxes = false;
     return set_geo(h, h->dynamics, M, offsets, px, py, c4);
+}
+
+int sfm_set_dynamic_boxes(SfmHandle* h, int M, const int32_t* offsets, const float* ux, const float* uy,
+                          const float* cx, const float* cy, const float* yaw_cos, const float* yaw_sin,
+                          const float* vx, const float* vy) {
+    if (!h) return SFM_ERR_INVALID;
+    if (M > 0 && (!cx || !cy || !yaw_cos || !yaw_sin)) return fail(h, SFM_ERR_INVALID, "box centre / yaw arrays are NULL");
+    std::vector<float4> c4((size_t)(M > 0 ? M : 0));
+    for (int k = 0; k < M; ++k) c4[k] = make_float4(cx[k], cy[k], vx ? vx[k] : 0.f, vy ? vy[k] : 0.f);
+    h->dyn_boxes = false;
+    int rc = set_geo(h, h->dynamics, M, offsets, ux, uy, c4);     // pts temporarily holds the local offsets
+    if (rc || M == 0) return rc;
+    const int P = h->dynamics.P;
+    std::vector<float2> rot((size_t)M);
+    for (int k = 0; k < M; ++k) rot[k] = make_float2(yaw_cos[k], yaw_sin[k]);
+    HIP_TRY(h, dev_realloc(h->dyn_local, (size_t)(P > 0 ? P : 1)));
+    HIP_TRY(h, dev_realloc(h->dyn_rot, (size_t)M));
+    if (P > 0) HIP_TRY(h, hipMemcpy(h->dyn_local, h->dynamics.pts, sizeof(float2) * (size_t)P, hipMemcpyDeviceToDevice));
+    HIP_TRY(h, hipMemcpy(h->dyn_rot, rot.data(), sizeof(float2) * (size_t)M, hipMemcpyHostToDevice));
+    HIP_TRY(h, launch_dynamic_boxes(h->dynamics.ctr, h->dynamics.off, h->dyn_local, h->dyn_rot, h->dynamics.pts, M,
+                                    h->prm.step_length, 0, h->stream));
+    h->dyn_boxes = true;
+    return SFM_OK;
+}
+
+int sfm_download_dynamic_obstacles(SfmHandle* h, float* cx, float* cy, float* px, float* py) {
+    int rc = bind(h);
+    if (rc) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const int M = h->dynamics.K, P = h->dynamics.P;
+    if (M == 0) return SFM_OK;
+    std::vector<float4> c((size_t)M);
+    std::vector<float2> p((size_t)(P > 0 ? P : 1));
+    HIP_TRY(h, hipMemcpy(c.data(), h->dynamics.ctr, sizeof(float4) * (size_t)M, hipMemcpyDeviceToHost));
+    if (P > 0) HIP_TRY(h, hipMemcpy(p.data(), h->dynamics.pts, sizeof(float2) * (size_t)P, hipMemcpyDeviceToHost));
+    for (int k = 0; k < M; ++k) { if (cx) cx[k] = c[k].x; if (cy) cy[k] = c[k].y; }
+    for (int q = 0; q < P; ++q) { if (px) px[q] = p[q].x; if (py) py[q] = p[q].y; }
+    return SFM_OK;
 }
 
 int sfm_upload_state(SfmHandle* h, int N, const float* x, const float* y, const float* z, const float* vx,
@@ -303,10 +349,10 @@ int sfm_upload_state(SfmHandle* h, int N, const float* x, const float* y, const 
     HIP_TRY(h, hipMemcpy(h->radius, rr.data(), sizeof(float) * (size_t)n_pad, hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->crossing, cm.data(), (size_t)n_pad, hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemset(h->draws, 0, sizeof(uint32_t) * (size_t)n_pad));
-    // slab of the symmetric path: n_t x (n_t*64) float2, only while it stays modest (<= 1 GiB)
+    // slab of the symmetric path: n_t x (n_t*64) float2 (8.6 GB at N = 262 144), up to 16 GiB of the 288 GB
     h->n_t = (N + WAVE - 1) / WAVE;
     const size_t need = (size_t)h->n_t * (size_t)h->n_t * WAVE;
-    if (!z3 && !rad && h->dpp_dir != 0 && h->sym_mode != 0 && need * sizeof(float2) <= ((size_t)1 << 30)) {
+    if (!z3 && !rad && h->dpp_dir != 0 && h->sym_mode != 0 && need * sizeof(float2) <= ((size_t)16 << 30)) {
         if (need > h->slab_cap) { HIP_TRY(h, dev_realloc(h->slab, need)); h->slab_cap = need; }
         if (h->n_t > h->tile_cap) { HIP_TRY(h, dev_realloc(h->tile_flag, (size_t)h->n_t)); h->tile_cap = h->n_t; }
         HIP_TRY(h, hipMemset(h->tile_flag, 0, sizeof(int) * (size_t)h->n_t));
@@ -414,6 +460,12 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags) {
             ++launches;
         }
         h->cur ^= 1;
+        // CARLA-free runs: the vehicles move between ticks (run_simulation.py:77-95)
+        if (h->dyn_boxes && (flags & SFM_TICK_INTEGRATE) && h->dynamics.K > 0) {
+            HIP_TRY(h, launch_dynamic_boxes(h->dynamics.ctr, h->dynamics.off, h->dyn_local, h->dyn_rot, h->dynamics.pts,
+                                            h->dynamics.K, h->prm.step_length, 1, h->stream));
+            ++launches;
+        }
     }
     HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
     h->timed_ticks = ticks;

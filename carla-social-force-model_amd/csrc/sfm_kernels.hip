@@ -774,6 +774,26 @@ __global__ __launch_bounds__(EPI_BLOCK) void sfm_sym_epilogue_kernel(const TickA
     }
 }
 
+// Dynamic obstacles on the device (obstacles.py:297-329 without the simulator): one thread per vehicle moves
+// the centre by dt*v (advance != 0) and regenerates its ring p = c + R(yaw) u.
+__global__ void sfm_dynamic_boxes_kernel(float4* __restrict__ ctr, const int* __restrict__ off,
+                                         const float2* __restrict__ local, const float2* __restrict__ rot,
+                                         float2* __restrict__ pts, int M, float dt, int advance) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= M) return;
+    float4 c = ctr[k];
+    if (advance) {
+        c.x = fmaf(dt, c.z, c.x);
+        c.y = fmaf(dt, c.w, c.y);
+        ctr[k] = c;
+    }
+    const float2 r = rot[k];                       // {cos yaw, sin yaw}
+    for (int p = off[k]; p < off[k + 1]; ++p) {
+        const float2 u = local[p];
+        pts[p] = make_float2(fmaf(r.x, u.x, fmaf(-r.y, u.y, c.x)), fmaf(r.y, u.x, fmaf(r.x, u.y, c.y)));
+    }
+}
+
 // get_arrived_peds (pedestrian_simulation.py:88-97) on the current device state.
 __global__ void sfm_arrived_kernel(const float4* __restrict__ pk, const float4* __restrict__ own, int N, float thr2,
                                    uint8_t* __restrict__ mask) {
@@ -841,6 +861,13 @@ int probe_dpp_direction(hipStream_t st) {
     bool up = true, down = true;
     for (int l = 0; l < 64; ++l) { up &= (h[l] == ((l + 1) & 63)); down &= (h[l] == ((l + 63) & 63)); }
     return up ? 1 : (down ? -1 : 0);
+}
+
+hipError_t launch_dynamic_boxes(float4* ctr, const int* off, const float2* local, const float2* rot, float2* pts, int M,
+                                float dt, int advance, hipStream_t st) {
+    if (M <= 0) return hipSuccess;
+    hipLaunchKernelGGL(sfm_dynamic_boxes_kernel, dim3((M + 63) / 64), dim3(64), 0, st, ctr, off, local, rot, pts, M, dt, advance);
+    return hipGetLastError();
 }
 
 hipError_t launch_arrived(const float4* pk, const float4* own, int N, float thr2, uint8_t* mask, hipStream_t st) {

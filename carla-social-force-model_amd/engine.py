@@ -152,6 +152,34 @@ class SfmEngine:
         self._check(self._lib.sfm_set_dynamic_obstacles(self._h, M, iptr(off), fptr(px), fptr(py), fptr(cx), fptr(cy),
                                                         fptr(vx), fptr(vy)), "sfm_set_dynamic_obstacles")
 
+    def set_dynamic_boxes(self, centers, yaws, extents, velocities, resolution=0.1):
+        """Vehicles as oriented boxes (centre (M,2), yaw rad (M,), half-extents (M,2), velocity (M,2)); ring
+        points are generated and advanced on the device (CARLA-free runs).  Ring-local offsets follow
+        generate_ellipse_border (obstacles.py:269-281)."""
+        from .scenarios import ring_local_offsets
+        M = len(centers)
+        if M == 0:
+            self._check(self._lib.sfm_set_dynamic_boxes(self._h, 0, *([None] * 9)), "sfm_set_dynamic_boxes")
+            return
+        locs = [ring_local_offsets(ex, ey, resolution) for ex, ey in np.asarray(extents, dtype=np.float64).reshape(M, 2)]
+        off, ux, uy = _csr(locs)
+        c = np.asarray(centers, dtype=np.float64).reshape(M, 2)
+        v = np.asarray(velocities, dtype=np.float64).reshape(M, 2)
+        yaw = np.asarray(yaws, dtype=np.float64).reshape(M)
+        arrs = [f32(c[:, 0]), f32(c[:, 1]), f32(np.cos(yaw)), f32(np.sin(yaw)), f32(v[:, 0]), f32(v[:, 1])]
+        self._dyn_shape = (M, int(off[-1]), off)
+        self._check(self._lib.sfm_set_dynamic_boxes(self._h, M, iptr(off), fptr(ux), fptr(uy), *(fptr(a) for a in arrs)),
+                    "sfm_set_dynamic_boxes")
+
+    def dynamic_obstacles(self):
+        """Current device-side vehicles as the reference's list of (center, ring) tuples."""
+        M, P, off = self._dyn_shape
+        cx, cy, px, py = np.zeros(M, np.float32), np.zeros(M, np.float32), np.zeros(P, np.float32), np.zeros(P, np.float32)
+        self._check(self._lib.sfm_download_dynamic_obstacles(self._h, fptr(cx), fptr(cy), fptr(px), fptr(py)),
+                    "sfm_download_dynamic_obstacles")
+        pts = np.stack([px, py], axis=1).astype(np.float64)
+        return [(np.array([cx[k], cy[k]], dtype=np.float64), pts[off[k]:off[k + 1]]) for k in range(M)]
+
     # ---- state ------------------------------------------------------------------------------------
     def upload_state(self, loc, vel, waypoint, target_speed, radius=None, crossing=None, planar=None):
         """loc, vel, waypoint: (N,3) float; target_speed, radius: (N,); crossing: (N,) bool.

@@ -81,6 +81,31 @@ def ellipse_ring(center, yaw, ex, ey, resolution=RESOLUTION, scale=np.sqrt(2.0))
     return _f32(ring)
 
 
+def ring_local_offsets(ex, ey, resolution=RESOLUTION, scale=np.sqrt(2.0)):
+    """The ellipse of generate_ellipse_border before the vehicle transform (obstacles.py:269-281), fp32."""
+    samples = max(6, int((2.0 * ex + 2.0 * ey) / resolution))
+    th = 2.0 * np.pi * np.arange(samples) / samples
+    return _f32(np.column_stack((ex * np.cos(th) * scale, ey * np.sin(th) * scale)))
+
+
+def place_ring_f32(center, yaw, local):
+    """p = c + R(yaw) u evaluated the way the device does (fp32, fused multiply-adds): the host-side twin of
+    sfm_dynamic_boxes_kernel, so CPU checks see bit-identical ring points."""
+    c32 = np.asarray(center, dtype=np.float32).astype(np.float64)
+    cs, sn = np.float64(np.float32(np.cos(yaw))), np.float64(np.float32(np.sin(yaw)))
+    u = np.asarray(local, dtype=np.float32).astype(np.float64)
+    fma = lambda a, b, c: np.float32(a * b + c).astype(np.float64)      # product of two fp32 is exact in f64
+    px = fma(cs, u[:, 0], fma(-sn, u[:, 1], c32[0]))
+    py = fma(sn, u[:, 0], fma(cs, u[:, 1], c32[1]))
+    return np.column_stack((px, py))
+
+
+def advance_center_f32(center, vel, dt):
+    c = np.asarray(center, dtype=np.float32).astype(np.float64)
+    v = np.asarray(vel, dtype=np.float32).astype(np.float64)
+    return np.float32(np.float64(np.float32(dt)) * v + c).astype(np.float64)
+
+
 def make_crowd(n, seed, density=0.25, jitter=0.8, z_spread=0.0):
     """Jittered-grid crowd.  Returns (loc, vel, waypoint, target_speed, radius,
     world_side)."""
@@ -139,7 +164,7 @@ def make_scenario(n, seed, n_borders=0, n_static=0, n_dynamic=0, z_spread=0.0, d
         c = _f32(rng.uniform(0.0, side, 2))
         yaw = rng.uniform(0.0, 2.0 * np.pi)
         sp = rng.uniform(0.0, 14.0)
-        sc.dynamic_obstacles.append((c, ellipse_ring(c, yaw, 2.4, 1.0)))
+        sc.dynamic_obstacles.append((c, place_ring_f32(c, yaw, ring_local_offsets(2.4, 1.0))))
         yaws.append(yaw)
         vels.append(_f32([sp * np.cos(yaw), sp * np.sin(yaw)]))
         exts.append([2.4, 1.0])
@@ -150,12 +175,12 @@ def make_scenario(n, seed, n_borders=0, n_static=0, n_dynamic=0, z_spread=0.0, d
 
 
 def advance_dynamic(sc: Scenario, dt):
-    """Move the vehicles one step and rebuild their rings (what get_dynamic_obstacles does per tick,
-    obstacles.py:297-329)."""
+    """Move the vehicles one step and rebuild their rings (what the simulator + get_dynamic_obstacles do per
+    tick, obstacles.py:297-329), in the device's fp32 arithmetic."""
     new = []
     for k, (c, _) in enumerate(sc.dynamic_obstacles):
-        c2 = _f32(np.asarray(c) + dt * sc.dynamic_vel[k])
-        new.append((c2, ellipse_ring(c2, sc.dynamic_yaw[k], *sc.dynamic_extent[k])))
+        c2 = advance_center_f32(c, sc.dynamic_vel[k], dt)
+        new.append((c2, place_ring_f32(c2, sc.dynamic_yaw[k], ring_local_offsets(*sc.dynamic_extent[k]))))
     sc.dynamic_obstacles = new
     return sc
 

@@ -52,7 +52,8 @@ class HipShardEngine:
         if sc.borders:
             e.set_borders(sc.borders, sc.border_centers, sc.border_lengths)
         e.set_static_obstacles(sc.static_obstacles)
-        e.set_dynamic_obstacles(sc.dynamic_obstacles, sc.dynamic_vel)
+        if len(sc.dynamic_obstacles):     # vehicles live on the device and move between ticks
+            e.set_dynamic_boxes([c for c, _ in sc.dynamic_obstacles], sc.dynamic_yaw, sc.dynamic_extent, sc.dynamic_vel)
         crossing = (sc.mode == 2) | (sc.mode == 3)
         e.upload_state(sc.loc, sc.vel, sc.waypoint, sc.target_speed, sc.radius, crossing)
         e.set_waypoint_stream(sc.seed, sc.world_side, 2.0)

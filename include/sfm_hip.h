@@ -92,6 +92,17 @@ int sfm_set_static_obstacles(SfmHandle* h, int M, const int32_t* offsets, const 
 int sfm_set_dynamic_obstacles(SfmHandle* h, int M, const int32_t* offsets, const float* px, const float* py,
                               const float* cx, const float* cy, const float* vx, const float* vy);
 
+/* Device-side form of get_dynamic_obstacles (obstacles.py:297-329) for CARLA-free runs:
+ * the vehicles are given once as oriented boxes -- ring-local offsets (the ellipse of obstacles.py:269-281 before
+ * the transform; CSR offsets[M+1], ux, uy), centre, cos/sin of the yaw, velocity.  Ring points
+ * p = c + R(yaw) u are generated on the device, and after every tick of sfm_run the centres advance by
+ * step_length * v and the rings are regenerated (what the simulator + get_dynamic_obstacles do between ticks). */
+int sfm_set_dynamic_boxes(SfmHandle* h, int M, const int32_t* offsets, const float* ux, const float* uy,
+                          const float* cx, const float* cy, const float* yaw_cos, const float* yaw_sin,
+                          const float* vx, const float* vy);
+/* Current dynamic-obstacle centres (M) and ring points (P) as the next tick will see them; NULL skips. */
+int sfm_download_dynamic_obstacles(SfmHandle* h, float* cx, float* cy, float* px, float* py);
+
 /* ---- state ----------------------------------------------------------------------------------------- */
 
 /* The numeric columns of PedState.state (pedestrian_state.py:17-19) as fp32 SoA: loc, vel, next_waypoint,

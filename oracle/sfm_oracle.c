@@ -58,8 +58,10 @@ static double moussaid(const OIx* p, const double* e, double dist, const double*
     F[1] += ft * t[0];
     if (!isnan(fv) && !isnan(ft)) {   /* magnitude x (1 + first-order fp32 angle-noise amplification / 1e-5), see sfm_oracle.py */
         const double res = 2.384185791015625e-07 / 1e-5, at = fabs(theta);
-        *mag += fabs(fv) * (1.0 + 2.0 * (p->n_prime * B) * (p->n_prime * B) * at * res)
-              + fabs(ft) * (1.0 + 2.0 * (p->n * B) * (p->n * B) * at * res);
+        const double xv = fabs(a) + (p->n_prime * B * theta) * (p->n_prime * B * theta);
+        const double xt = fabs(a) + (p->n * B * theta) * (p->n * B * theta);
+        *mag += fabs(fv) * (1.0 + (2.0 * (p->n_prime * B) * (p->n_prime * B) * at + xv) * res)
+              + fabs(ft) * (1.0 + (2.0 * (p->n * B) * (p->n * B) * at + xt) * res);
     }
     if (theta_tol > 0.0 && (fabs(theta) < theta_tol || fabs(fabs(raw) - M_PI) < theta_tol) && !isnan(ft)) return 2.0 * fabs(ft);
     return 0.0;

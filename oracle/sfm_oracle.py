@@ -141,8 +141,11 @@ def moussaid_term(e, dist, dv, p: Interaction, theta_tol=0.0):
     # The scale reported for a term is its magnitude times (1 + that amplification / 1e-5), so "1e-5 of the
     # scale" means 1e-5 plus the unavoidable first-order fp32 angle noise (parity section).
     with np.errstate(invalid="ignore", over="ignore"):
-        amp_v = 2.0 * np.square(p.n_prime * B) * np.abs(theta) * FP32_ANGLE_RESOLUTION / 1e-5
-        amp_t = 2.0 * np.square(p.n * B) * np.abs(theta) * FP32_ANGLE_RESOLUTION / 1e-5
+        # ... and exp(x) carries |x| times the rounding error of x (three fp32 roundings ~ 2^-22 relative)
+        x_v = np.abs(a) + np.square(p.n_prime * B * theta)
+        x_t = np.abs(a) + np.square(p.n * B * theta)
+        amp_v = (2.0 * np.square(p.n_prime * B) * np.abs(theta) + x_v) * FP32_ANGLE_RESOLUTION / 1e-5
+        amp_t = (2.0 * np.square(p.n * B) * np.abs(theta) + x_t) * FP32_ANGLE_RESOLUTION / 1e-5
         mag = np.abs(f_v) * (1.0 + amp_v) + np.abs(f_th) * (1.0 + amp_t)
     return F, expo, mag
 

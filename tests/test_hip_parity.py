@@ -266,3 +266,37 @@ def test_multi_tick_resync_and_free_run():
         assert np.median(np.linalg.norm(dloc - free[0], axis=1)) < 1e-3
     finally:
         eng.close()
+
+
+def test_device_side_dynamic_obstacles_track_the_host_twin():
+    """vehicles given as boxes, rings generated and advanced on the device.
+    Ring points must equal the host twin (scenarios.place_ring_f32 / advance_dynamic) bit for bit, and a
+    10-tick run must match the oracle stepping with the host-advanced geometry."""
+    n = 400
+    sc = scenarios.make_scenario(n, 606, n_dynamic=12)
+    cfg = default_sfm_config(("acceleration_force", "pedestrian_force", "dynamic_obstacle_force"))
+    prm = O.OracleParams.from_config(cfg)
+    eng = SfmEngine(cfg, 0.05)
+    try:
+        eng.set_dynamic_boxes([c for c, _ in sc.dynamic_obstacles], sc.dynamic_yaw, sc.dynamic_extent, sc.dynamic_vel)
+        eng.upload_state(sc.loc, sc.vel, sc.waypoint, sc.target_speed, sc.radius, None)
+        eng.set_waypoint_stream(sc.seed, sc.world_side, 2.0)
+        loc, vel, wp = sc.loc.copy(), sc.vel.copy(), sc.waypoint.copy()
+        draws = np.zeros(n, dtype=np.int64)
+        for k in range(10):
+            dev = eng.dynamic_obstacles()
+            for (c_d, r_d), (c_h, r_h) in zip(dev, sc.dynamic_obstacles):
+                assert np.array_equal(c_d, c_h) and np.array_equal(r_d, r_h), f"tick {k}"
+            geom = O.Geometry(dynamic_obstacles=sc.dynamic_obstacles, dynamic_vel=sc.dynamic_vel)
+            with np.errstate(all="ignore"):
+                oloc, ovel, owp, draws = O.free_step(loc, vel, wp, sc.target_speed, sc.radius, np.zeros(n, bool), draws,
+                                                     geom, prm, 0.05, 2.0, sc.seed, sc.world_side)
+            eng.run(1, redraw=True)
+            dloc, dvel, dwp = eng.state()
+            assert np.max(np.abs(dvel - ovel)) <= 1e-4 * np.max(np.abs(ovel)), f"tick {k}"
+            loc, vel = dloc, dvel
+            wp = np.concatenate([dwp, np.zeros((n, 1))], axis=1)
+            draws = eng.draw_counts().astype(np.int64)
+            scenarios.advance_dynamic(sc, 0.05)
+    finally:
+        eng.close()
