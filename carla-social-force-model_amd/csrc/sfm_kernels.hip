@@ -595,10 +595,13 @@ __global__ __launch_bounds__(BLOCK) void sfm_pair_sym_kernel(const float4* __res
         };
         // sigma = 32 on a diagonal tile meets every unordered pair {l, l+32} in BOTH lanes: one-sided there
         const bool tail_one_sided = diag && (sig0 + nsteps - 1 == 32);        // uniform
-        const int n_sym = tail_one_sided ? nsteps - 1 : nsteps;
-#pragma unroll 2
-        for (int s = 0; s < n_sym; ++s) step(true);
-        if (tail_one_sided) step(false);
+        if (nsteps == 16) {                      // the normal case: fixed trip count, steps interleaved 3-way
+#pragma unroll 3
+            for (int s = 0; s < 15; ++s) step(true);
+            if (tail_one_sided) step(false); else step(true);
+        } else {                                 // timing probe (SymArgs::debug_steps)
+            for (int s = 0; s < nsteps; ++s) step(true);
+        }
         i_end_loc = (lane + sa.dir * (sig0 + nsteps)) & (WAVE - 1);
         flag = wave_max(flag);
         if (flag >= COINCIDENT_RINV && lane == 0) { sa.tile_flag[ta] = 1; sa.tile_flag[tb] = 1; }
