@@ -15,7 +15,9 @@
 namespace sfm {
 hipError_t launch_tick(int ipw, int team, bool z3, bool rad, const TickArgs& a, hipStream_t st);
 hipError_t launch_arrived(const float4* pk, const float4* own, int N, float thr2, uint8_t* mask, hipStream_t st);
-hipError_t launch_sym_tick(const TickArgs& a, const SymArgs& sa, hipStream_t st);
+hipError_t launch_sym_pair(const TickArgs& a, const SymArgs& sa, hipStream_t st);
+hipError_t launch_sym_epilogue(const TickArgs& a, const SymArgs& sa, hipStream_t st);
+hipError_t launch_geometry(bool rad, const TickArgs& a, hipStream_t st);
 int probe_dpp_direction(hipStream_t st);
 hipError_t launch_dynamic_boxes(float4* ctr, const int* off, const float2* local, const float2* rot, float2* pts, int M,
                                 float dt, int advance, hipStream_t st);
@@ -29,6 +31,7 @@ struct DevGeo {
     int* off = nullptr;
     float2* pts = nullptr;
     float4* ctr = nullptr;
+    float4* seg = nullptr;
     int K = 0;
     int P = 0;
 };
@@ -51,6 +54,7 @@ struct SfmHandle {
     uint8_t* arrived = nullptr;
     uint32_t* draws = nullptr;
     float* rec = nullptr;                 // [6][3][N]
+    float* geo = nullptr;                 // [6][N_pad] geometry forces of the current tick
     bool rec_valid = false;
     DevGeo borders, statics, dynamics;
     float2* dyn_local = nullptr;          // device-side vehicles: ring-local offsets [P] and {cos,sin} yaw [M]
@@ -71,6 +75,10 @@ struct SfmHandle {
     float world_side = 0.f, arrive_thr = 2.0f;
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // geometry forces run on a side stream beside the pair kernel (they only need the tick's input state)
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool overlap_geo = true;
     int timed_ticks = 0, timed_launches = 0;
     bool timing_valid = false;
     int ipw_last = 0;
@@ -150,6 +158,13 @@ int sfm_create(const SfmParams* params, int device_id, SfmHandle** out) {
         delete h;
         return fail(nullptr, SFM_ERR_HIP, "hipEventCreate failed");
     }
+    if (hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
+        h->aux = nullptr;
+        h->overlap_geo = false;
+    }
+    if (getenv("SFM_NO_OVERLAP")) h->overlap_geo = false;
     const char* ov = getenv("SFM_IPW");
     if (ov) h->ipw_override = atoi(ov);
     ov = getenv("SFM_TEAM");
@@ -165,6 +180,7 @@ static void free_geo(DevGeo& g) {
     if (g.off) hipFree(g.off);
     if (g.pts) hipFree(g.pts);
     if (g.ctr) hipFree(g.ctr);
+    if (g.seg) hipFree(g.seg);
     g = DevGeo();
 }
 
@@ -179,11 +195,15 @@ int sfm_destroy(SfmHandle* h) {
     if (h->arrived) hipFree(h->arrived);
     if (h->draws) hipFree(h->draws);
     if (h->rec) hipFree(h->rec);
+    if (h->geo) hipFree(h->geo);
     if (h->dyn_local) hipFree(h->dyn_local);
     if (h->dyn_rot) hipFree(h->dyn_rot);
     if (h->slab) hipFree(h->slab);
     if (h->tile_flag) hipFree(h->tile_flag);
     free_geo(h->borders); free_geo(h->statics); free_geo(h->dynamics);
+    if (h->aux) { hipStreamSynchronize(h->aux); hipStreamDestroy(h->aux); }
+    if (h->ev_fork) hipEventDestroy(h->ev_fork);
+    if (h->ev_join) hipEventDestroy(h->ev_join);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
     delete h;
@@ -238,7 +258,34 @@ int sfm_set_borders(SfmHandle* h, int K, const int32_t* offsets, const float* px
     std::vector<float4> c4((size_t)(K > 0 ? K : 0));
     for (int k = 0; k < K; ++k)
         c4[k] = make_float4(cx[k], cy[k], (float)((double)cull_len[k] * (double)cull_len[k]), 0.f);
-    return set_geo(h, h->borders, K, offsets, px, py, c4);
+    int rc = set_geo(h, h->borders, K, offsets, px, py, c4);
+    if (rc || K == 0) return rc;
+    // chord first->last point and the largest deviation of the polyline from it: a distance lower bound that
+    // lets the kernel skip borders whose term is below 2^-40 a (rounded up so the bound stays a bound)
+    std::vector<float4> seg((size_t)2 * K);
+    for (int k = 0; k < K; ++k) {
+        const int o0 = offsets[k], o1 = offsets[k + 1];
+        double ax = 0, ay = 0, abx = 0, aby = 0, inv = 0, dev = 0;
+        if (o1 > o0) {
+            ax = px[o0]; ay = py[o0];
+            abx = (double)px[o1 - 1] - ax; aby = (double)py[o1 - 1] - ay;
+            const double ab2 = abx * abx + aby * aby;
+            inv = ab2 > 0 ? 1.0 / ab2 : 0.0;
+            for (int p = o0; p < o1; ++p) {
+                const double qx = px[p] - ax, qy = py[p] - ay;
+                double t = (qx * abx + qy * aby) * inv;
+                t = t < 0 ? 0 : (t > 1 ? 1 : t);
+                const double ex_ = qx - t * abx, ey_ = qy - t * aby;
+                const double d = std::sqrt(ex_ * ex_ + ey_ * ey_);
+                if (d > dev) dev = d;
+            }
+        }
+        seg[2 * k] = make_float4((float)ax, (float)ay, (float)abx, (float)aby);
+        seg[2 * k + 1] = make_float4((float)inv, (float)(dev * 1.0001 + 1e-4), 0.f, 0.f);
+    }
+    HIP_TRY(h, dev_realloc(h->borders.seg, (size_t)2 * K));
+    HIP_TRY(h, hipMemcpy(h->borders.seg, seg.data(), sizeof(float4) * (size_t)2 * K, hipMemcpyHostToDevice));
+    return SFM_OK;
 }
 
 int sfm_set_static_obstacles(SfmHandle* h, int M, const int32_t* offsets, const float* px, const float* py,
@@ -322,6 +369,7 @@ int sfm_upload_state(SfmHandle* h, int N, const float* x, const float* y, const 
         HIP_TRY(h, dev_realloc(h->arrived, (size_t)n_pad));
         HIP_TRY(h, dev_realloc(h->draws, (size_t)n_pad));
         HIP_TRY(h, dev_realloc(h->rec, (size_t)n_pad * 18));
+        HIP_TRY(h, dev_realloc(h->geo, (size_t)n_pad * 6));
         h->cap = n_pad;
     }
     h->N = N; h->N_pad = n_pad; h->z3 = z3; h->rad = rad;
@@ -403,7 +451,10 @@ static void fill_args(SfmHandle* h, TickArgs& a, uint32_t flags) {
     a.crossing = h->crossing;
     a.draws = h->draws;
     a.rec = (flags & SFM_TICK_RECORD_FORCES) ? h->rec : nullptr;
-    a.N = h->N; a.i_begin = h->i_begin; a.i_end = h->i_end;
+    a.N = h->N; a.N_pad = h->N_pad; a.i_begin = h->i_begin; a.i_end = h->i_end;
+    const bool any_geo = (p.enabled[SFM_FORCE_BORDER] && h->borders.K > 0) || (p.enabled[SFM_FORCE_STATIC_OBSTACLE] && h->statics.K > 0) ||
+                         (p.enabled[SFM_FORCE_DYNAMIC_OBSTACLE] && h->dynamics.K > 0);
+    a.geo = any_geo ? h->geo : nullptr;
     a.flags = flags;
     a.en_acc = p.enabled[SFM_FORCE_ACCELERATION];
     a.en_ped = p.enabled[SFM_FORCE_PEDESTRIAN];
@@ -415,15 +466,16 @@ static void fill_args(SfmHandle* h, TickArgs& a, uint32_t flags) {
     a.dyn = fold(p.dynamic_obstacle);
     a.border_a = p.border_a;
     a.border_nlb = (float)(-1.4426950408889634 / (double)p.border_b);
+    a.border_skip = (p.border_b > 0.f && p.border_a != 0.f) ? (float)(40.0 * 0.6931471805599453 * (double)p.border_b) : 0.f;
     a.inv_tau = (float)(1.0 / (double)p.tau);
     a.dt = p.step_length;
     a.max_speed_factor = p.max_speed_factor;
     a.seed = h->seed;
     a.world_side = h->world_side;
     a.arrive_thr2 = (float)((double)h->arrive_thr * (double)h->arrive_thr);
-    a.borders = Geo{h->borders.off, h->borders.pts, h->borders.ctr, h->borders.K};
-    a.statics = Geo{h->statics.off, h->statics.pts, h->statics.ctr, h->statics.K};
-    a.dynamics = Geo{h->dynamics.off, h->dynamics.pts, h->dynamics.ctr, h->dynamics.K};
+    a.borders = Geo{h->borders.off, h->borders.pts, h->borders.ctr, h->borders.seg, h->borders.K};
+    a.statics = Geo{h->statics.off, h->statics.pts, h->statics.ctr, nullptr, h->statics.K};
+    a.dynamics = Geo{h->dynamics.off, h->dynamics.pts, h->dynamics.ctr, nullptr, h->dynamics.K};
 }
 
 static int run_ticks(SfmHandle* h, int ticks, uint32_t flags) {
@@ -451,9 +503,25 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags) {
     for (int t = 0; t < ticks; ++t) {
         TickArgs a;
         fill_args(h, a, flags);
+        // border / obstacle forces only need the tick's input state.  With the symmetric path they run on the
+        // side stream BESIDE the pair kernel (memory-latency-bound next to VALU-bound) and join before the
+        // epilogue; the ordered kernel consumes them itself, so there they simply run first.
+        const bool fork = a.geo && n_local > 0 && sym && h->overlap_geo;
+        if (fork) {
+            HIP_TRY(h, hipEventRecord(h->ev_fork, h->stream));
+            HIP_TRY(h, hipStreamWaitEvent(h->aux, h->ev_fork, 0));
+            HIP_TRY(h, launch_geometry(h->rad, a, h->aux));
+            HIP_TRY(h, hipEventRecord(h->ev_join, h->aux));
+            ++launches;
+        } else if (a.geo && n_local > 0) {
+            HIP_TRY(h, launch_geometry(h->rad, a, h->stream));
+            ++launches;
+        }
         if (sym) {
             SymArgs sa{h->slab, h->tile_flag, h->n_t, h->n_t * WAVE, h->dpp_dir, getenv("SFM_DEBUG_STEPS") ? atoi(getenv("SFM_DEBUG_STEPS")) : -1};
-            HIP_TRY(h, launch_sym_tick(a, sa, h->stream));
+            HIP_TRY(h, launch_sym_pair(a, sa, h->stream));
+            if (fork) HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
+            HIP_TRY(h, launch_sym_epilogue(a, sa, h->stream));
             launches += 2;
         } else if (n_local > 0) {
             HIP_TRY(h, launch_tick(ipw, team, h->z3, h->rad, a, h->stream));

@@ -30,6 +30,7 @@ struct Geo {                  // CSR polylines / rings
     const int* off;           // [K+1]
     const float2* pts;        // [P] {x, y}
     const float4* ctr;        // [K] borders: {cx, cy, section_length^2, 0}; obstacles: {cx, cy, vx, vy}
+    const float4* seg;        // [2K] borders only: {ax, ay, abx, aby}, {1/|ab|^2, max deviation from segment ab, 0, 0}
     int K;
 };
 
@@ -44,12 +45,14 @@ struct TickArgs {
     const uint8_t* crossing;  // border-force mask
     uint32_t* draws;          // waypoint draw counters
     float* rec;               // optional per-force record, layout [6][3][N]
-    int N, i_begin, i_end;
+    float* geo;               // geometry forces of this tick, layout [6][N_pad]: {fbx,fby,fsx,fsy,fdx,fdy}; null = none
+    int N, N_pad, i_begin, i_end;
     uint32_t flags;
     // parameters
     int en_acc, en_ped, en_border, en_static, en_dynamic;
     IxConst ped, stat, dyn;
     float border_a, border_nlb;   // a, -log2(e)/b
+    float border_skip;            // distance beyond which a border term is < 2^-40 a (40 ln2 * b), <= 0: never skip
     float inv_tau, dt, max_speed_factor;
     // waypoint stream
     uint32_t seed;

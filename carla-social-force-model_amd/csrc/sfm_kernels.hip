@@ -140,27 +140,68 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-// First nearest sampled point of polyline [o0,o1) to (x,y): np.argmin's first-minimum rule
-// (forces.py:154,228).  Wave-cooperative; returns the (uniform) point index.
-__device__ __forceinline__ int wave_nearest(const float2* __restrict__ pts, int o0, int o1, float x, float y,
-                                            int lane) {
-    float bd = __builtin_inff();
+// ---- nearest sampled point of a polyline: np.argmin's first-minimum rule (forces.py:154,228) -------------
+// A wave serves FOUR polylines at once: each row of 16 lanes scans one polyline [o0,o1) (o0/o1 are per-lane,
+// equal within a row) and the (distance, index, point) minimum is all-reduced inside the row with four DPP
+// row rotations -- VALU moves, no LDS traffic, and four independent load chains in flight per wave.  An empty
+// polyline yields a far-away sentinel point whose force term underflows to exactly 0.
+template <int R>
+__device__ __forceinline__ float ror16(float v) {
+    const int b = __float_as_int(v);
+    return __int_as_float(__builtin_amdgcn_update_dpp(b, b, 0x120 + R /* row_ror:R */, 0xf, 0xf, false));
+}
+template <int R>
+__device__ __forceinline__ int ror16(int v) {
+    return __builtin_amdgcn_update_dpp(v, v, 0x120 + R, 0xf, 0xf, false);
+}
+template <int R>
+__device__ __forceinline__ void argmin_step(float& bd, int& bi, float& bx, float& by) {
+    const float od = ror16<R>(bd), ox = ror16<R>(bx), oy = ror16<R>(by);
+    const int oi = ror16<R>(bi);
+    const bool take = (od < bd) | ((od == bd) & (oi < bi));
+    bd = take ? od : bd;
+    bi = take ? oi : bi;
+    bx = take ? ox : bx;
+    by = take ? oy : by;
+}
+__device__ __forceinline__ float2 row_nearest(const float2* __restrict__ pts, int o0, int o1, float x, float y, int gl) {
+    float bd = __builtin_inff(), bx = 3.0e15f, by = 3.0e15f;
     int bi = 0x7fffffff;
-    for (int p = o0 + lane; p < o1; p += WAVE) {
-        const float2 q = pts[p];
-        const float ddx = x - q.x, ddy = y - q.y;
-        const float dd = fmaf(ddx, ddx, ddy * ddy);
-        if (dd < bd) { bd = dd; bi = p; }
+    // four independent loads per trip (indices clamped into the polyline, results masked), compared in
+    // ascending index order so the first minimum wins
+    for (int p = o0 + gl; p < o1; p += 64) {
+        const int last = o1 - 1;
+        const float2 q0 = pts[p], q1 = pts[min(p + 16, last)], q2 = pts[min(p + 32, last)], q3 = pts[min(p + 48, last)];
+        const float d0 = fmaf(x - q0.x, x - q0.x, (y - q0.y) * (y - q0.y));
+        const float d1 = fmaf(x - q1.x, x - q1.x, (y - q1.y) * (y - q1.y));
+        const float d2 = fmaf(x - q2.x, x - q2.x, (y - q2.y) * (y - q2.y));
+        const float d3 = fmaf(x - q3.x, x - q3.x, (y - q3.y) * (y - q3.y));
+        if (d0 < bd) { bd = d0; bi = p; bx = q0.x; by = q0.y; }
+        if ((p + 16 < o1) & (d1 < bd)) { bd = d1; bi = p + 16; bx = q1.x; by = q1.y; }
+        if ((p + 32 < o1) & (d2 < bd)) { bd = d2; bi = p + 32; bx = q2.x; by = q2.y; }
+        if ((p + 48 < o1) & (d3 < bd)) { bd = d3; bi = p + 48; bx = q3.x; by = q3.y; }
     }
+    argmin_step<8>(bd, bi, bx, by);
+    argmin_step<4>(bd, bi, bx, by);
+    argmin_step<2>(bd, bi, bx, by);
+    argmin_step<1>(bd, bi, bx, by);
+    return make_float2(bx, by);
+}
+
+// Pops up to four set bits of m (uniform) and returns the one belonging to this lane's row, or -1.
+__device__ __forceinline__ int pop4(unsigned long long& m, int row, int& n_popped) {
+    int mine = -1;
+    n_popped = 0;
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        const float od = __shfl_xor(bd, m);
-        const int oi = __shfl_xor(bi, m);
-        const bool take = (od < bd) | ((od == bd) & (oi < bi));
-        bd = take ? od : bd;
-        bi = take ? oi : bi;
+    for (int g = 0; g < 4; ++g) {
+        if (m) {
+            const int b = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            if (row == g) mine = b;
+            ++n_popped;
+        }
     }
-    return uniform(bi);
+    return mine;
 }
 
 __device__ __forceinline__ uint32_t mix32(uint32_t a) {   // lowbias32
@@ -173,12 +214,17 @@ __device__ __forceinline__ float waypoint_coord(uint32_t seed, uint32_t ped, uin
 }
 
 // BorderForce._get_force for one pedestrian (forces.py:145-167), wave-cooperative.
+// Borders whose every point is provably farther than 40 ln2 * b (+ radius) contribute less than 2^-40 a each
+// and are not scanned: the bound is the distance to the chord first-last point minus the polyline's largest
+// deviation from that chord (exact for the straight config borders of obstacles.py:344-355).
 template <bool RAD>
 __device__ __forceinline__ void border_force(const TickArgs& a, float xi, float yi, float ri, int lane,
                                              float& fx, float& fy) {
     const Geo& g = a.borders;
+    const int row = lane >> 4, gl = lane & 15;
     float ax = 0.0f, ay = 0.0f, spx = 0.0f, spy = 0.0f;
     int cnt = 0;
+    const float skip = a.border_skip > 0.0f ? a.border_skip + (RAD ? fmaxf(ri, 0.0f) : 0.0f) : __builtin_inff();
     auto flush = [&]() {
         if (lane < cnt) {
             const float ddx = xi - spx, ddy = yi - spy;
@@ -191,25 +237,45 @@ __device__ __forceinline__ void border_force(const TickArgs& a, float xi, float 
         }
         cnt = 0;
     };
-    for (int kb = 0; kb < g.K; kb += WAVE) {
-        const int k = kb + lane;
-        bool keep = false;
-        if (k < g.K) {
-            const float4 c = g.ctr[k];
+    // Pass 1 (no dependences between trips, so the loads pipeline): every lane tests its own borders and
+    // remembers the survivors as bits (trip t <-> bit t).  Pass 2 walks the bits, four borders per wave trip.
+    for (int base = 0; base < g.K; base += WAVE * 64) {
+        const int trips = min(64, (g.K - base + WAVE - 1) / WAVE);
+        unsigned long long bits = 0ull;
+#pragma unroll 4
+        for (int t = 0; t < trips; ++t) {
+            const int k = base + t * WAVE + lane;
+            const float4 c = g.ctr[min(k, g.K - 1)];
             const float ddx = xi - c.x, ddy = yi - c.y;
-            keep = fmaf(ddx, ddx, ddy * ddy) < c.z;                         // |x - center| < section_length, strict (:149-150)
+            const bool keep = (k < g.K) & (fmaf(ddx, ddx, ddy * ddy) < c.z);   // |x - center| < section_length, strict (:149-150)
+            bits |= (unsigned long long)keep << t;
         }
-        unsigned long long m = __ballot(keep);
-        while (m) {
-            const int b = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            const int kk = kb + b;
-            const int o0 = g.off[kk], o1 = g.off[kk + 1];
-            if (o1 <= o0) continue;
-            const int bi = wave_nearest(g.pts, o0, o1, xi, yi, lane);
-            const float2 p = g.pts[bi];
-            if (lane == cnt) { spx = p.x; spy = p.y; }
-            if (++cnt == WAVE) flush();
+        // refine the (few) survivors of this lane with the chord bound
+        for (unsigned long long b = bits; b;) {
+            const int t = __ffsll((long long)b) - 1;
+            b &= b - 1;
+            const int k = base + t * WAVE + lane;
+            const float4 s0 = g.seg[2 * k], s1 = g.seg[2 * k + 1];
+            const float px = xi - s0.x, py = yi - s0.y;
+            const float tt = fminf(fmaxf(fmaf(px, s0.z, py * s0.w) * s1.x, 0.0f), 1.0f);
+            const float qx = fmaf(-tt, s0.z, px), qy = fmaf(-tt, s0.w, py);
+            if (sqrtf(fmaf(qx, qx, qy * qy)) - s1.y > skip) bits &= ~(1ull << t);
+        }
+        for (int t = 0; t < trips; ++t) {
+            const int kb = base + t * WAVE;
+            unsigned long long m = __ballot((bits >> t) & 1ull);
+            while (m) {
+                int nb;
+                const int mine = pop4(m, row, nb);
+                int o0 = 0, o1 = 0;
+                if (mine >= 0) { o0 = g.off[kb + mine]; o1 = g.off[kb + mine + 1]; }
+                const float2 p = row_nearest(g.pts, o0, o1, xi, yi, gl);
+                const int src = ((lane - cnt) & 3) << 4;                        // any lane of row (lane - cnt)
+                const float sx = __shfl(p.x, src), sy = __shfl(p.y, src);
+                if (lane >= cnt && lane < cnt + nb) { spx = sx; spy = sy; }
+                cnt += nb;
+                if (cnt > WAVE - 4) flush();
+            }
         }
     }
     flush();
@@ -221,6 +287,7 @@ __device__ __forceinline__ void border_force(const TickArgs& a, float xi, float 
 template <bool RAD>
 __device__ __forceinline__ void obstacle_force(const Geo& g, const IxConst& c, bool moving, float xi, float yi,
                                                float vxi, float vyi, float ri, int lane, float& fx, float& fy) {
+    const int row = lane >> 4, gl = lane & 15;
     float gx = 0.0f, gy = 0.0f, gz = 0.0f, spx = 0.0f, spy = 0.0f, svx = 0.0f, svy = 0.0f;
     int cnt = 0;
     auto flush = [&]() {
@@ -242,22 +309,54 @@ __device__ __forceinline__ void obstacle_force(const Geo& g, const IxConst& c, b
         }
         unsigned long long m = __ballot(keep);
         while (m) {
-            const int b = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            const int kk = kb + b;
-            const int o0 = g.off[kk], o1 = g.off[kk + 1];
-            if (o1 <= o0) continue;
-            const int bi = wave_nearest(g.pts, o0, o1, xi, yi, lane);
-            const float2 p = g.pts[bi];
-            const float ovx = moving ? __shfl(ck.z, b) : 0.0f;              // static obstacles: v = 0 (:212-213)
-            const float ovy = moving ? __shfl(ck.w, b) : 0.0f;
-            if (lane == cnt) { spx = p.x; spy = p.y; svx = ovx; svy = ovy; }
-            if (++cnt == WAVE) flush();
+            int nb;
+            const int mine = pop4(m, row, nb);
+            int o0 = 0, o1 = 0;
+            if (mine >= 0) { o0 = g.off[kb + mine]; o1 = g.off[kb + mine + 1]; }
+            const float2 p = row_nearest(g.pts, o0, o1, xi, yi, gl);
+            // velocity of this row's obstacle (static obstacles: v = 0, forces.py:212-213)
+            const float ovx = moving ? __shfl(ck.z, max(mine, 0)) : 0.0f;
+            const float ovy = moving ? __shfl(ck.w, max(mine, 0)) : 0.0f;
+            const int src = ((lane - cnt) & 3) << 4;
+            const float sx = __shfl(p.x, src), sy = __shfl(p.y, src);
+            const float tvx = moving ? __shfl(ovx, src) : 0.0f, tvy = moving ? __shfl(ovy, src) : 0.0f;
+            if (lane >= cnt && lane < cnt + nb) { spx = sx; spy = sy; svx = tvx; svy = tvy; }
+            cnt += nb;
+            if (cnt > WAVE - 4) flush();
         }
     }
     flush();
     fx = c.negA * wave_sum(gx);
     fy = c.negA * wave_sum(gy);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// geometry forces: border + static + dynamic obstacles, one wave per pedestrian
+// ------------------------------------------------------------------------------------------------------
+// Per kept polyline the work is a short dependent chain (offsets -> points -> argmin butterfly -> exp), so
+// this phase is latency-bound; giving every pedestrian its own wave (8 waves per SIMD resident) hides it far
+// better than doing it inside the pair kernels' epilogues.  It depends only on the tick's input state, so it
+// runs first and leaves {fbx,fby,fsx,fsy,fdx,fdy} in geo[6][N_pad] for the epilogue of either pair path.
+template <bool RAD>
+__global__ __launch_bounds__(BLOCK) void sfm_geometry_kernel(const TickArgs a) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wave = uniform((int)(threadIdx.x >> 6));
+    const int i = a.i_begin + blockIdx.x * WAVES_PER_BLOCK + wave;
+    if (i >= a.i_end) return;
+    const float4 s = a.pk_cur[i];
+    const float x = uniform(s.x), y = uniform(s.y), vx = uniform(s.z), vy = uniform(s.w);
+    const float r = uniform(a.own[i].w);
+    float fbx = 0.f, fby = 0.f, fsx = 0.f, fsy = 0.f, fdx = 0.f, fdy = 0.f;
+    if (a.en_border && a.borders.K > 0 && !(a.crossing && a.crossing[i]))    // forces.py:140-141,176-177
+        border_force<RAD>(a, x, y, r, lane, fbx, fby);
+    if (a.en_static && a.statics.K > 0)
+        obstacle_force<RAD>(a.statics, a.stat, false, x, y, vx, vy, r, lane, fsx, fsy);
+    if (a.en_dynamic && a.dynamics.K > 0)
+        obstacle_force<RAD>(a.dynamics, a.dyn, true, x, y, vx, vy, r, lane, fdx, fdy);
+    if (lane < 6) {
+        const float v = lane == 0 ? fbx : lane == 1 ? fby : lane == 2 ? fsx : lane == 3 ? fsy : lane == 4 ? fdx : fdy;
+        a.geo[(size_t)lane * a.N_pad + i] = v;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -454,15 +553,14 @@ __global__ __launch_bounds__(BLOCK) void sfm_tick_kernel(const TickArgs a) {
         const float4 o = a.own[i];
         float wx = uniform(o.x), wy = uniform(o.y);
         const float ts = uniform(o.z);
-        if (!RAD) r = uniform(o.w);
+        (void)r;
 
         float fbx = 0.f, fby = 0.f, fsx = 0.f, fsy = 0.f, fdx = 0.f, fdy = 0.f;
-        if (a.en_border && a.borders.K > 0 && !(a.crossing && a.crossing[i]))    // forces.py:140-141,176-177
-            border_force<RAD>(a, x, y, r, lane, fbx, fby);
-        if (a.en_static && a.statics.K > 0)
-            obstacle_force<RAD>(a.statics, a.stat, false, x, y, vx, vy, r, lane, fsx, fsy);
-        if (a.en_dynamic && a.dynamics.K > 0)
-            obstacle_force<RAD>(a.dynamics, a.dyn, true, x, y, vx, vy, r, lane, fdx, fdy);
+        if (a.geo) {                                // border / obstacle forces from sfm_geometry_kernel
+            const size_t np_ = (size_t)a.N_pad;
+            fbx = a.geo[0 * np_ + i]; fby = a.geo[1 * np_ + i]; fsx = a.geo[2 * np_ + i];
+            fsy = a.geo[3 * np_ + i]; fdx = a.geo[4 * np_ + i]; fdy = a.geo[5 * np_ + i];
+        }
 
         // AccelerationForce (forces.py:46-53, stateutils.py:7-15)
         float fax = 0.f, fay = 0.f, faz = 0.f;
@@ -635,15 +733,14 @@ __global__ __launch_bounds__(BLOCK) void sfm_pair_sym_kernel(const float4* __res
 
 // Epilogue of the symmetric path: one workgroup of 16 waves per tile of 64 pedestrians.  The waves split the
 // partner tiles of the slab column sum (all loads of a wave in flight at once, combined in LDS in a fixed
-// order), run the geometry forces (a wave per pedestrian, as in the ordered kernel), and wave 0 integrates
-// the 64 pedestrians lane-parallel with coalesced stores.  Latency-bound by design: few, short chains.
+// order) and wave 0 integrates the 64 pedestrians lane-parallel with coalesced loads and stores (geometry
+// forces come from sfm_geometry_kernel).  Latency-bound by design: few, short chains.
 constexpr int EPI_WAVES = 16;
 constexpr int EPI_BLOCK = EPI_WAVES * WAVE;
 
 template <bool RAD>
 __global__ __launch_bounds__(EPI_BLOCK) void sfm_sym_epilogue_kernel(const TickArgs a, const SymArgs sa) {
     __shared__ float2 s_sum[EPI_WAVES][WAVE];
-    __shared__ float s_geo[WAVE][6];
     __shared__ float2 s_exact[WAVE];
     const int tid = threadIdx.x;
     const int lane = tid & (WAVE - 1);
@@ -675,7 +772,6 @@ __global__ __launch_bounds__(EPI_BLOCK) void sfm_sym_epilogue_kernel(const TickA
         }
     }
     s_sum[wave][lane] = acc;
-    for (int p = tid; p < WAVE * 6; p += EPI_BLOCK) (&s_geo[0][0])[p] = 0.0f;
     const bool exact = a.en_ped && (sa.tile_flag[t] != 0);       // uniform per workgroup
     __syncthreads();
 
@@ -701,28 +797,7 @@ __global__ __launch_bounds__(EPI_BLOCK) void sfm_sym_epilogue_kernel(const TickA
             if (lane == 0) s_exact[p] = make_float2(gx, gy);
         }
     }
-    // 3. geometry forces, a wave per pedestrian
-    const bool any_geo = (a.en_border && a.borders.K > 0) || (a.en_static && a.statics.K > 0) || (a.en_dynamic && a.dynamics.K > 0);
-    if (any_geo) {
-        for (int p = wave; p < WAVE; p += EPI_WAVES) {
-            const int ip = t * WAVE + p;
-            if (ip >= N) break;
-            const float4 si = a.pk_cur[ip];
-            const float x = uniform(si.x), y = uniform(si.y), vx = uniform(si.z), vy = uniform(si.w);
-            const float r = uniform(a.own[ip].w);
-            float fbx = 0.f, fby = 0.f, fsx = 0.f, fsy = 0.f, fdx = 0.f, fdy = 0.f;
-            if (a.en_border && a.borders.K > 0 && !(a.crossing && a.crossing[ip]))
-                border_force<RAD>(a, x, y, r, lane, fbx, fby);
-            if (a.en_static && a.statics.K > 0)
-                obstacle_force<RAD>(a.statics, a.stat, false, x, y, vx, vy, r, lane, fsx, fsy);
-            if (a.en_dynamic && a.dynamics.K > 0)
-                obstacle_force<RAD>(a.dynamics, a.dyn, true, x, y, vx, vy, r, lane, fdx, fdy);
-            if (lane == 0) {
-                s_geo[p][0] = fbx; s_geo[p][1] = fby; s_geo[p][2] = fsx; s_geo[p][3] = fsy; s_geo[p][4] = fdx; s_geo[p][5] = fdy;
-            }
-        }
-    }
-    if (exact || any_geo) __syncthreads();
+    if (exact) __syncthreads();
     if (wave != 0) return;
     if (exact && lane == 0) sa.tile_flag[t] = 0;      // re-armed for the next tick
     if (i >= N) return;
@@ -733,8 +808,12 @@ __global__ __launch_bounds__(EPI_BLOCK) void sfm_sym_epilogue_kernel(const TickA
     for (int w = 1; w < EPI_WAVES; ++w) { const float2 b = s_sum[w][lane]; g.x += b.x; g.y += b.y; }
     if (exact) g = s_exact[lane];
     const float fpx = a.en_ped ? a.ped.negA * g.x : 0.f, fpy = a.en_ped ? a.ped.negA * g.y : 0.f;
-    const float fbx = s_geo[lane][0], fby = s_geo[lane][1], fsx = s_geo[lane][2], fsy = s_geo[lane][3];
-    const float fdx = s_geo[lane][4], fdy = s_geo[lane][5];
+    float fbx = 0.f, fby = 0.f, fsx = 0.f, fsy = 0.f, fdx = 0.f, fdy = 0.f;
+    if (a.geo) {
+        const size_t np_ = (size_t)a.N_pad;
+        fbx = a.geo[0 * np_ + i]; fby = a.geo[1 * np_ + i]; fsx = a.geo[2 * np_ + i];
+        fsy = a.geo[3 * np_ + i]; fdx = a.geo[4 * np_ + i]; fdy = a.geo[5 * np_ + i];
+    }
     const float x = st.x, y = st.y, vx = st.z, vy = st.w, ts = o.z;
     float wx = o.x, wy = o.y;
     float fax = 0.f, fay = 0.f;
@@ -841,13 +920,23 @@ hipError_t launch_tick(int ipw, int team, bool z3, bool rad, const TickArgs& a, 
     return team == 4 ? launch_team<4>(ipw, z3, rad, a, st) : launch_team<1>(ipw, z3, rad, a, st);
 }
 
-hipError_t launch_sym_tick(const TickArgs& a, const SymArgs& sa, hipStream_t st) {
+hipError_t launch_geometry(bool rad, const TickArgs& a, hipStream_t st) {
+    const int n_local = a.i_end - a.i_begin;
+    if (n_local <= 0) return hipSuccess;
+    const int grid = (n_local + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+    if (rad) hipLaunchKernelGGL((sfm_geometry_kernel<true>), dim3(grid), dim3(BLOCK), 0, st, a);
+    else hipLaunchKernelGGL((sfm_geometry_kernel<false>), dim3(grid), dim3(BLOCK), 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_sym_pair(const TickArgs& a, const SymArgs& sa, hipStream_t st) {
+    if (a.N <= 1 || !a.en_ped) return hipSuccess;
+    hipLaunchKernelGGL(sfm_pair_sym_kernel, dim3(sa.n_t, sa.n_t / 2 + 1), dim3(BLOCK), 0, st, a.pk_cur, a.ped, sa);
+    return hipGetLastError();
+}
+
+hipError_t launch_sym_epilogue(const TickArgs& a, const SymArgs& sa, hipStream_t st) {
     if (a.N <= 0) return hipSuccess;
-    if (a.en_ped && a.N > 1) {
-        hipLaunchKernelGGL(sfm_pair_sym_kernel, dim3(sa.n_t, sa.n_t / 2 + 1), dim3(BLOCK), 0, st, a.pk_cur, a.ped, sa);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return e;
-    }
     hipLaunchKernelGGL((sfm_sym_epilogue_kernel<false>), dim3(sa.n_t), dim3(EPI_BLOCK), 0, st, a, sa);
     return hipGetLastError();
 }
