@@ -18,6 +18,7 @@ hipError_t launch_arrived(const float4* pk, const float4* own, int N, float thr2
 hipError_t launch_sym_pair(const TickArgs& a, const SymArgs& sa, hipStream_t st);
 hipError_t launch_sym_epilogue(const TickArgs& a, const SymArgs& sa, hipStream_t st);
 hipError_t launch_geometry(bool rad, const TickArgs& a, hipStream_t st);
+hipError_t launch_tile_bounds(const float4* pk, int N, float4* box, float* vmax, hipStream_t st);
 int probe_dpp_direction(hipStream_t st);
 hipError_t launch_dynamic_boxes(float4* ctr, const int* off, const float2* local, const float2* rot, float2* pts, int M,
                                 float dt, int advance, hipStream_t st);
@@ -69,6 +70,14 @@ struct SfmHandle {
     int tile_cap = 0;
     int dpp_dir = 0;
     int sym_mode = -1;                     // SFM_SYM: 0 off, 1 on when eligible, -1 auto
+    // tile-granular cutoff of provably negligible pedestrian pairs
+    float4* tile_box = nullptr;
+    float* tile_vmax = nullptr;
+    uint32_t* work = nullptr;
+    int* work_count = nullptr;
+    size_t work_cap = 0;
+    int cut_mode = -1;                     // SFM_CUTOFF: 0 off, 1 on, -1 auto (N >= 8192)
+    float r_max = 0.f;
     bool used_sym = false;
 
     uint32_t seed = 0;
@@ -171,6 +180,8 @@ int sfm_create(const SfmParams* params, int device_id, SfmHandle** out) {
     if (ov) h->team_override = atoi(ov);
     ov = getenv("SFM_SYM");
     if (ov) h->sym_mode = atoi(ov);
+    ov = getenv("SFM_CUTOFF");
+    if (ov) h->cut_mode = atoi(ov);
     h->dpp_dir = probe_dpp_direction(nullptr);
     *out = h;
     return SFM_OK;
@@ -200,6 +211,10 @@ int sfm_destroy(SfmHandle* h) {
     if (h->dyn_rot) hipFree(h->dyn_rot);
     if (h->slab) hipFree(h->slab);
     if (h->tile_flag) hipFree(h->tile_flag);
+    if (h->tile_box) hipFree(h->tile_box);
+    if (h->tile_vmax) hipFree(h->tile_vmax);
+    if (h->work) hipFree(h->work);
+    if (h->work_count) hipFree(h->work_count);
     free_geo(h->borders); free_geo(h->statics); free_geo(h->dynamics);
     if (h->aux) { hipStreamSynchronize(h->aux); hipStreamDestroy(h->aux); }
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
@@ -405,6 +420,16 @@ int sfm_upload_state(SfmHandle* h, int N, const float* x, const float* y, const 
         if (h->n_t > h->tile_cap) { HIP_TRY(h, dev_realloc(h->tile_flag, (size_t)h->n_t)); h->tile_cap = h->n_t; }
         HIP_TRY(h, hipMemset(h->tile_flag, 0, sizeof(int) * (size_t)h->n_t));
     }
+    // cutoff bookkeeping: per-tile box / max speed, and the work list of the symmetric kernel
+    h->r_max = 0.f;
+    if (rad) for (int i = 0; i < N; ++i) h->r_max = std::fmax(h->r_max, radius[i]);
+    HIP_TRY(h, dev_realloc(h->tile_box, (size_t)h->n_t));
+    HIP_TRY(h, dev_realloc(h->tile_vmax, (size_t)h->n_t));
+    {
+        const size_t items = (size_t)h->n_t * (size_t)(h->n_t / 2 + 1);
+        if (h->n_t < 65536 && items > h->work_cap) { HIP_TRY(h, dev_realloc(h->work, items)); h->work_cap = items; }
+        if (!h->work_count) HIP_TRY(h, dev_realloc(h->work_count, (size_t)1));
+    }
     return SFM_OK;
 }
 
@@ -455,6 +480,12 @@ static void fill_args(SfmHandle* h, TickArgs& a, uint32_t flags) {
     const bool any_geo = (p.enabled[SFM_FORCE_BORDER] && h->borders.K > 0) || (p.enabled[SFM_FORCE_STATIC_OBSTACLE] && h->statics.K > 0) ||
                          (p.enabled[SFM_FORCE_DYNAMIC_OBSTACLE] && h->dynamics.K > 0);
     a.geo = any_geo ? h->geo : nullptr;
+    const bool cut = p.enabled[SFM_FORCE_PEDESTRIAN] && h->tile_box && h->N <= 64 * 64 * WAVE &&
+                     (h->cut_mode == 1 || (h->cut_mode < 0 && h->N >= 8192)) && p.pedestrian.gamma > 0.f && p.pedestrian.lambda >= 0.f;
+    a.tile_box = cut ? h->tile_box : nullptr;
+    a.tile_vmax = cut ? h->tile_vmax : nullptr;
+    a.cut_scale = (float)((double)p.pedestrian.gamma * 41.0 * 0.6931471805599453 * 1.001);
+    a.cut_pad = h->rad ? 2.0f * h->r_max * 1.001f : 0.f;
     a.flags = flags;
     a.en_acc = p.enabled[SFM_FORCE_ACCELERATION];
     a.en_ped = p.enabled[SFM_FORCE_PEDESTRIAN];
@@ -506,6 +537,10 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags) {
         // border / obstacle forces only need the tick's input state.  With the symmetric path they run on the
         // side stream BESIDE the pair kernel (memory-latency-bound next to VALU-bound) and join before the
         // epilogue; the ordered kernel consumes them itself, so there they simply run first.
+        if (a.tile_box) {                         // boxes / speeds of this tick's input state (all tiles)
+            HIP_TRY(h, launch_tile_bounds(a.pk_cur, h->N, h->tile_box, h->tile_vmax, h->stream));
+            ++launches;
+        }
         const bool fork = a.geo && n_local > 0 && sym && h->overlap_geo;
         if (fork) {
             HIP_TRY(h, hipEventRecord(h->ev_fork, h->stream));
@@ -518,7 +553,9 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags) {
             ++launches;
         }
         if (sym) {
-            SymArgs sa{h->slab, h->tile_flag, h->n_t, h->n_t * WAVE, h->dpp_dir, getenv("SFM_DEBUG_STEPS") ? atoi(getenv("SFM_DEBUG_STEPS")) : -1};
+            SymArgs sa{h->slab, h->tile_flag, h->n_t, h->n_t * WAVE, h->dpp_dir, getenv("SFM_DEBUG_STEPS") ? atoi(getenv("SFM_DEBUG_STEPS")) : -1,
+                       a.tile_box ? h->work : nullptr, a.tile_box ? h->work_count : nullptr};
+            if (sa.work) launches += 1;
             HIP_TRY(h, launch_sym_pair(a, sa, h->stream));
             if (fork) HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
             HIP_TRY(h, launch_sym_epilogue(a, sa, h->stream));

@@ -58,6 +58,11 @@ struct TickArgs {
     uint32_t seed;
     float world_side, arrive_thr2;
     Geo borders, statics, dynamics;
+    // pedestrian-force cutoff at tile granularity (null = off): see tiles_negligible()
+    const float4* tile_box;   // [n_t] {xmin, ymin, xmax, ymax} of the real pedestrians of each 64-tile
+    const float* tile_vmax;   // [n_t] largest speed in the tile
+    float cut_scale;          // gamma * 41 ln 2 (with margin): distance per unit of (lambda*(va+vb)+1)
+    float cut_pad;            // 2 * largest radius when use_ped_radius, else 0
 };
 
 // Symmetric (antisymmetry-exploiting) pedestrian-force path, single shard only.
@@ -68,6 +73,8 @@ struct SymArgs {
     int stride;          // n_t * 64
     int dir;             // lane direction of the DPP wavefront rotate (+1: lane l receives lane l+1), calibrated at init
     int debug_steps;     // < 0: normal; >= 0: run only this many systolic steps per wave (timing probe, wrong results)
+    const uint32_t* work;    // cutoff on: compacted list of (bx | shift << 16) tile-pair items, else null
+    const int* work_count;
 };
 
 }  // namespace sfm

@@ -140,6 +140,24 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// ------------------------------------------------------------------------------------------------------
+// provably negligible tile pairs
+// ------------------------------------------------------------------------------------------------------
+// |f_ij| <= A (e1 + e2) <= 2 A exp(-d_eff / B),  B = gamma |D|,  |D| = |lambda (v_i - v_j) + e| <= lambda (|v_i| + |v_j|) + 1.
+// So if the bounding boxes of two 64-pedestrian tiles are farther apart than
+//     gamma (lambda (vmax_a + vmax_b) + 1) * 41 ln 2   (+ 2 r_max with use_ped_radius)
+// every one of their 4096 terms is below 2^-40 A and the tile pair is not evaluated.  The bound uses the
+// actual speeds of THIS tick (sfm_tile_bounds_kernel), so it holds for any state the caller uploads; a
+// crowd in random index order simply has overlapping boxes and nothing is skipped.  The test is symmetric in
+// its two tiles bit for bit, so the pair kernel and the epilogue always agree on it.
+__device__ __forceinline__ bool tiles_negligible(const float4 ba, const float va, const float4 bb, const float vb,
+                                                 const float lam, const float cut_scale, const float cut_pad) {
+    const float gx = fmaxf(0.0f, fmaxf(ba.x - bb.z, bb.x - ba.z));
+    const float gy = fmaxf(0.0f, fmaxf(ba.y - bb.w, bb.y - ba.w));
+    const float reach = fmaf(cut_scale, fmaf(lam, va + vb, 1.0f), cut_pad);
+    return fmaf(gx, gx, gy * gy) > reach * reach;
+}
+
 // ---- nearest sampled point of a polyline: np.argmin's first-minimum rule (forces.py:154,228) -------------
 // A wave serves FOUR polylines at once: each row of 16 lanes scans one polyline [o0,o1) (o0/o1 are per-lane,
 // equal within a row) and the (distance, index, point) minimum is all-reduced inside the row with four DPP
@@ -402,8 +420,33 @@ __global__ __launch_bounds__(BLOCK) void sfm_tick_kernel(const TickArgs a) {
     if (a.en_ped && N > 1) {
         float flag = 0.0f;                       // max rsq(d2) over valid pairs: coincidence detector
 
+        // cutoff: bit t of lane l says whether partner tile 64 t + l has to be evaluated against this wave's
+        // rows (they all lie in one 64-tile); see tiles_negligible()
+        const bool cut = a.tile_box != nullptr && N <= 64 * 64 * WAVE;
+        unsigned int keep_lo = 0xffffffffu, keep_hi = 0xffffffffu;
+        if (cut) {
+            const int n_t = (N + WAVE - 1) / WAVE, ti = min(ibase, a.i_end - 1) >> 6;
+            const float4 bt = a.tile_box[ti];
+            const float vt = a.tile_vmax[ti];
+            unsigned long long km = 0ull;
+            for (int t = 0; t * WAVE < n_t; ++t) {
+                const int u = t * WAVE + lane;
+                const bool keep = (u < n_t) && !tiles_negligible(bt, vt, a.tile_box[min(u, n_t - 1)], a.tile_vmax[min(u, n_t - 1)],
+                                                                 a.ped.lam, a.cut_scale, a.cut_pad);
+                km |= (unsigned long long)keep << t;
+            }
+            keep_lo = (unsigned int)km;
+            keep_hi = (unsigned int)(km >> 32);
+        }
+
         // 64 pairs x IPW rows: lane's record pj against the wave's rows
         auto step = [&](int j0, const float4 pj, float zj, float vzj, float rj) {
+            if (cut) {
+                const int u = j0 >> 6;                                    // uniform
+                const unsigned int w = (u >> 6) < 32 ? __builtin_amdgcn_readlane(keep_lo, u & 63)
+                                                     : __builtin_amdgcn_readlane(keep_hi, u & 63);
+                if (!((w >> ((u >> 6) & 31)) & 1u)) return;
+            }
             const bool clean = (j0 + WAVE <= N) && (ibase + IPW <= j0 || ibase >= j0 + WAVE);   // uniform
             if (clean) {
 #pragma unroll
@@ -618,6 +661,47 @@ __global__ __launch_bounds__(BLOCK) void sfm_tick_kernel(const TickArgs a) {
     }
 }
 
+__global__ __launch_bounds__(WAVE) void sfm_tile_bounds_kernel(const float4* __restrict__ pk, int N, float4* __restrict__ box,
+                                                               float* __restrict__ vmax) {
+    const int t = blockIdx.x, lane = threadIdx.x;
+    const int i = t * WAVE + lane;
+    const float inf = __builtin_inff();
+    float x0 = inf, y0 = inf, x1 = -inf, y1 = -inf, v = 0.0f;
+    if (i < N) {
+        const float4 s = pk[i];
+        x0 = x1 = s.x; y0 = y1 = s.y;
+        v = sqrtf(fmaf(s.z, s.z, s.w * s.w)) * 1.000001f;      // rounded up: the bound must stay a bound
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        x0 = fminf(x0, __shfl_xor(x0, m)); y0 = fminf(y0, __shfl_xor(y0, m));
+        x1 = fmaxf(x1, __shfl_xor(x1, m)); y1 = fmaxf(y1, __shfl_xor(y1, m));
+        v = fmaxf(v, __shfl_xor(v, m));
+    }
+    if (lane == 0) { box[t] = make_float4(x0, y0, x1, y1); vmax[t] = v; }
+}
+
+// Compacts the tile-pair items the symmetric kernel has to evaluate: one candidate per thread, same (bx, shift)
+// enumeration as the kernel's 2-D grid.  Diagonal items are always kept.
+__global__ void sfm_pair_list_kernel(const float4* __restrict__ box, const float* __restrict__ vmax, int n_t, float lam,
+                                     float cut_scale, float cut_pad, uint32_t* __restrict__ work, int* __restrict__ count) {
+    const int bx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int shift = blockIdx.y;
+    if (bx >= n_t) return;
+    bool keep;
+    if (shift == 0) {
+        keep = bx < ((n_t + 1) >> 1);
+    } else {
+        keep = !(!(n_t & 1) && shift == (n_t >> 1) && bx >= (n_t >> 1));
+        if (keep) {
+            int tb = bx + shift;
+            if (tb >= n_t) tb -= n_t;
+            keep = !tiles_negligible(box[bx], vmax[bx], box[tb], vmax[tb], lam, cut_scale, cut_pad);
+        }
+    }
+    if (keep) work[atomicAdd(count, 1)] = (uint32_t)bx | ((uint32_t)shift << 16);
+}
+
 // ------------------------------------------------------------------------------------------------------
 // symmetric pedestrian force: every unordered pair once (F_ji = -F_ij), systolic over the wavefront
 // ------------------------------------------------------------------------------------------------------
@@ -651,13 +735,16 @@ __global__ __launch_bounds__(BLOCK) void sfm_pair_sym_kernel(const float4* __res
     const int wave = uniform(tid >> 6);
     const int n_t = sa.n_t;
     const int half_up = (n_t + 1) >> 1;
-    const int shift = blockIdx.y;                 // tile distance: 0 = diagonal blocks
-    const int bx = blockIdx.x;
+    // work items: the (bx, shift) of the 2-D grid, or -- cutoff on -- entries of the compacted list, strided
+    const int n_items = sa.work ? *sa.work_count : 1;
+  for (int item = sa.work ? (int)blockIdx.x : 0; item < n_items; item += (sa.work ? (int)gridDim.x : 1)) {
+    int shift = blockIdx.y, bx = blockIdx.x;      // shift = tile distance: 0 = diagonal items
+    if (sa.work) { const uint32_t w = sa.work[item]; bx = (int)(w & 0xffffu); shift = (int)(w >> 16); }
     int ta, tb, sig0, nsteps;
     bool diag = false;
     if (shift == 0) {
         // diagonal tiles are half the work (32 steps): two of them share a workgroup, two waves each
-        if (bx >= half_up) return;
+        if (bx >= half_up) return;                    // (never in the list)
         ta = (wave < 2) ? bx : bx + half_up;
         if (ta >= n_t) { ta = -1; }
         tb = ta;
@@ -729,6 +816,8 @@ __global__ __launch_bounds__(BLOCK) void sfm_pair_sym_kernel(const float4* __res
             sa.slab[(size_t)ta * sa.stride + tb * WAVE + p] = make_float2(((a0.x + a1.x) + a2.x) + a3.x, ((a0.y + a1.y) + a2.y) + a3.y);
         }
     }
+    if (sa.work) __syncthreads();                 // LDS is reused by the next item
+  }
 }
 
 // Epilogue of the symmetric path: one workgroup of 16 waves per tile of 64 pedestrians.  The waves split the
@@ -754,9 +843,30 @@ __global__ __launch_bounds__(EPI_BLOCK) void sfm_sym_epilogue_kernel(const TickA
     uint32_t nd0 = 0;
     if (wave == 0 && i < N) { st = a.pk_cur[i]; o = a.own[i]; if (a.flags & 2u) nd0 = a.draws[i]; }
 
-    // 1. slab column sums: wave w takes partner tiles w, w+16, ...
+    // 1. slab column sums
     float2 acc = make_float2(0.f, 0.f);
-    if (a.en_ped) {
+    if (a.en_ped && a.tile_box) {
+        // cutoff on: each wave owns a contiguous range of partner tiles; its lanes test 64 of them at a time
+        // and only the rows of evaluated tile pairs are read (ascending order, deterministic)
+        const float2* col = sa.slab + i;
+        const float4 bt = a.tile_box[t];
+        const float vt = a.tile_vmax[t];
+        const int per = (((sa.n_t + EPI_WAVES - 1) / EPI_WAVES) + WAVE - 1) / WAVE * WAVE;
+        const int u_end = min(sa.n_t, (wave + 1) * per);
+        for (int ub = wave * per; ub < u_end; ub += WAVE) {
+            const int u = ub + lane;
+            bool keep = false;
+            if (u < u_end) keep = !tiles_negligible(bt, vt, a.tile_box[u], a.tile_vmax[u], a.ped.lam, a.cut_scale, a.cut_pad);
+            unsigned long long m = __ballot(keep);
+            while (m) {
+                const int b = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const float2 v = col[(size_t)(ub + b) * sa.stride];
+                acc.x += v.x;
+                acc.y += v.y;
+            }
+        }
+    } else if (a.en_ped) {                                   // wave w takes partner tiles w, w+16, ...
         const float2* col = sa.slab + i;
         int u = wave;
         for (; u + 3 * EPI_WAVES < sa.n_t; u += 4 * EPI_WAVES) {          // 4 independent loads in flight
@@ -931,7 +1041,25 @@ hipError_t launch_geometry(bool rad, const TickArgs& a, hipStream_t st) {
 
 hipError_t launch_sym_pair(const TickArgs& a, const SymArgs& sa, hipStream_t st) {
     if (a.N <= 1 || !a.en_ped) return hipSuccess;
+    if (sa.work) {
+        // cutoff on: compact the tile pairs that have to be evaluated, then a resident grid strides over them
+        hipError_t e = hipMemsetAsync(const_cast<int*>(sa.work_count), 0, sizeof(int), st);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(sfm_pair_list_kernel, dim3((sa.n_t + 255) / 256, sa.n_t / 2 + 1), dim3(256), 0, st, a.tile_box,
+                           a.tile_vmax, sa.n_t, a.ped.lam, a.cut_scale, a.cut_pad, const_cast<uint32_t*>(sa.work),
+                           const_cast<int*>(sa.work_count));
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(sfm_pair_sym_kernel, dim3(256 * 8 * 2), dim3(BLOCK), 0, st, a.pk_cur, a.ped, sa);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(sfm_pair_sym_kernel, dim3(sa.n_t, sa.n_t / 2 + 1), dim3(BLOCK), 0, st, a.pk_cur, a.ped, sa);
+    return hipGetLastError();
+}
+
+hipError_t launch_tile_bounds(const float4* pk, int N, float4* box, float* vmax, hipStream_t st) {
+    if (N <= 0) return hipSuccess;
+    hipLaunchKernelGGL(sfm_tile_bounds_kernel, dim3((N + WAVE - 1) / WAVE), dim3(WAVE), 0, st, pk, N, box, vmax);
     return hipGetLastError();
 }
 
