@@ -231,12 +231,21 @@ __device__ __forceinline__ float waypoint_coord(uint32_t seed, uint32_t ped, uin
     return (float)(h >> 8) * 5.9604644775390625e-08f * side;   // 2^-24
 }
 
+// A candidate list restricts which polylines a pedestrian tests: `list` (LDS, ascending polyline indices) holds
+// the polylines that can pass the cull for SOME pedestrian of the tile; null = all K.  The per-pedestrian
+// tests below are exact either way, so results do not depend on the list (only the time does).
+struct Cand {
+    const int* list;
+    int count;
+    __device__ __forceinline__ int at(int c) const { return list ? list[c] : c; }
+};
+
 // BorderForce._get_force for one pedestrian (forces.py:145-167), wave-cooperative.
 // Borders whose every point is provably farther than 40 ln2 * b (+ radius) contribute less than 2^-40 a each
 // and are not scanned: the bound is the distance to the chord first-last point minus the polyline's largest
 // deviation from that chord (exact for the straight config borders of obstacles.py:344-355).
 template <bool RAD>
-__device__ __forceinline__ void border_force(const TickArgs& a, float xi, float yi, float ri, int lane,
+__device__ __forceinline__ void border_force(const TickArgs& a, const Cand cand, float xi, float yi, float ri, int lane,
                                              float& fx, float& fy) {
     const Geo& g = a.borders;
     const int row = lane >> 4, gl = lane & 15;
@@ -255,24 +264,25 @@ __device__ __forceinline__ void border_force(const TickArgs& a, float xi, float 
         }
         cnt = 0;
     };
-    // Pass 1 (no dependences between trips, so the loads pipeline): every lane tests its own borders and
+    // Pass 1 (no dependences between trips, so the loads pipeline): every lane tests its own candidates and
     // remembers the survivors as bits (trip t <-> bit t).  Pass 2 walks the bits, four borders per wave trip.
-    for (int base = 0; base < g.K; base += WAVE * 64) {
-        const int trips = min(64, (g.K - base + WAVE - 1) / WAVE);
+    for (int base = 0; base < cand.count; base += WAVE * 64) {
+        const int trips = min(64, (cand.count - base + WAVE - 1) / WAVE);
         unsigned long long bits = 0ull;
 #pragma unroll 4
         for (int t = 0; t < trips; ++t) {
-            const int k = base + t * WAVE + lane;
-            const float4 c = g.ctr[min(k, g.K - 1)];
+            const int cidx = base + t * WAVE + lane;
+            const int k = cand.at(min(cidx, cand.count - 1));
+            const float4 c = g.ctr[k];
             const float ddx = xi - c.x, ddy = yi - c.y;
-            const bool keep = (k < g.K) & (fmaf(ddx, ddx, ddy * ddy) < c.z);   // |x - center| < section_length, strict (:149-150)
+            const bool keep = (cidx < cand.count) & (fmaf(ddx, ddx, ddy * ddy) < c.z);   // |x - center| < section_length, strict (:149-150)
             bits |= (unsigned long long)keep << t;
         }
         // refine the (few) survivors of this lane with the chord bound
         for (unsigned long long b = bits; b;) {
             const int t = __ffsll((long long)b) - 1;
             b &= b - 1;
-            const int k = base + t * WAVE + lane;
+            const int k = cand.at(base + t * WAVE + lane);
             const float4 s0 = g.seg[2 * k], s1 = g.seg[2 * k + 1];
             const float px = xi - s0.x, py = yi - s0.y;
             const float tt = fminf(fmaxf(fmaf(px, s0.z, py * s0.w) * s1.x, 0.0f), 1.0f);
@@ -280,13 +290,13 @@ __device__ __forceinline__ void border_force(const TickArgs& a, float xi, float 
             if (sqrtf(fmaf(qx, qx, qy * qy)) - s1.y > skip) bits &= ~(1ull << t);
         }
         for (int t = 0; t < trips; ++t) {
-            const int kb = base + t * WAVE;
+            const int cb = base + t * WAVE;
             unsigned long long m = __ballot((bits >> t) & 1ull);
             while (m) {
                 int nb;
                 const int mine = pop4(m, row, nb);
                 int o0 = 0, o1 = 0;
-                if (mine >= 0) { o0 = g.off[kb + mine]; o1 = g.off[kb + mine + 1]; }
+                if (mine >= 0) { const int kk = cand.at(cb + mine); o0 = g.off[kk]; o1 = g.off[kk + 1]; }
                 const float2 p = row_nearest(g.pts, o0, o1, xi, yi, gl);
                 const int src = ((lane - cnt) & 3) << 4;                        // any lane of row (lane - cnt)
                 const float sx = __shfl(p.x, src), sy = __shfl(p.y, src);
@@ -303,8 +313,8 @@ __device__ __forceinline__ void border_force(const TickArgs& a, float xi, float 
 
 // ObstacleForce._get_force for one pedestrian (forces.py:217-275), wave-cooperative.
 template <bool RAD>
-__device__ __forceinline__ void obstacle_force(const Geo& g, const IxConst& c, bool moving, float xi, float yi,
-                                               float vxi, float vyi, float ri, int lane, float& fx, float& fy) {
+__device__ __forceinline__ void obstacle_force(const Geo& g, const Cand cand, const IxConst& c, bool moving, float xi,
+                                               float yi, float vxi, float vyi, float ri, int lane, float& fx, float& fy) {
     const int row = lane >> 4, gl = lane & 15;
     float gx = 0.0f, gy = 0.0f, gz = 0.0f, spx = 0.0f, spy = 0.0f, svx = 0.0f, svy = 0.0f;
     int cnt = 0;
@@ -316,11 +326,13 @@ __device__ __forceinline__ void obstacle_force(const Geo& g, const IxConst& c, b
         }
         cnt = 0;
     };
-    for (int kb = 0; kb < g.K; kb += WAVE) {
-        const int k = kb + lane;
+    for (int cb = 0; cb < cand.count; cb += WAVE) {
+        const int cidx = cb + lane;
         bool keep = false;
         float4 ck = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (k < g.K) {
+        int k = 0;
+        if (cidx < cand.count) {
+            k = cand.at(cidx);
             ck = g.ctr[k];
             const float ddx = xi - ck.x, ddy = yi - ck.y;
             keep = fmaf(ddx, ddx, ddy * ddy) < c.thr2;                      // |x - c_k| < perception_threshold (:222-223)
@@ -329,8 +341,9 @@ __device__ __forceinline__ void obstacle_force(const Geo& g, const IxConst& c, b
         while (m) {
             int nb;
             const int mine = pop4(m, row, nb);
+            const int kk = __shfl(k, max(mine, 0));
             int o0 = 0, o1 = 0;
-            if (mine >= 0) { o0 = g.off[kb + mine]; o1 = g.off[kb + mine + 1]; }
+            if (mine >= 0) { o0 = g.off[kk]; o1 = g.off[kk + 1]; }
             const float2 p = row_nearest(g.pts, o0, o1, xi, yi, gl);
             // velocity of this row's obstacle (static obstacles: v = 0, forces.py:212-213)
             const float ovx = moving ? __shfl(ck.z, max(mine, 0)) : 0.0f;
@@ -349,31 +362,84 @@ __device__ __forceinline__ void obstacle_force(const Geo& g, const IxConst& c, b
 }
 
 // ------------------------------------------------------------------------------------------------------
-// geometry forces: border + static + dynamic obstacles, one wave per pedestrian
+// geometry forces: border + static + dynamic obstacles, one workgroup per tile of 64 pedestrians
 // ------------------------------------------------------------------------------------------------------
-// Per kept polyline the work is a short dependent chain (offsets -> points -> argmin butterfly -> exp), so
-// this phase is latency-bound; giving every pedestrian its own wave (8 waves per SIMD resident) hides it far
-// better than doing it inside the pair kernels' epilogues.  It depends only on the tick's input state, so it
-// runs first and leaves {fbx,fby,fsx,fsy,fdx,fdy} in geo[6][N_pad] for the epilogue of either pair path.
+// Per kept polyline the work is a short dependent chain (offsets -> points -> argmin butterfly -> exp), so this
+// phase is latency-bound; it gets its own kernel (many waves in flight) instead of riding in the pair kernels'
+// epilogues, depends only on the tick's input state, and leaves {fbx,fby,fsx,fsy,fdx,fdy} in geo[6][N_pad].
+// Culling is hierarchical: wave 0 first tests every polyline against the TILE's bounding box (grown by the
+// cull radius) and compacts the survivors, in index order, into an LDS candidate list; each pedestrian then
+// runs its exact tests on the candidates only.  Compact tiles (a crowd in spatial index order) shrink the list
+// by the ratio world area / neighbourhood area; a scrambled crowd keeps every polyline and loses nothing.
+constexpr int GEO_CAND_MAX = 2048;
+constexpr int GEO_WAVES = 16;                 // 4 pedestrians per wave: enough waves in flight to hide the load chains
+constexpr int GEO_BLOCK = GEO_WAVES * WAVE;
+
+__device__ __forceinline__ int build_candidates(const Geo& g, bool borders, float thr2, float x0, float y0, float x1, float y1,
+                                                int lane, int* list) {
+    int n = 0;                                                       // uniform
+    for (int kb = 0; kb < g.K; kb += WAVE) {
+        const int k = kb + lane;
+        bool keep = false;
+        if (k < g.K) {
+            const float4 c = g.ctr[k];
+            const float gx = fmaxf(0.0f, fmaxf(x0 - c.x, c.x - x1)), gy = fmaxf(0.0f, fmaxf(y0 - c.y, c.y - y1));
+            // superset of the per-pedestrian test |x - c| < R: the box point nearest to c is at least as near
+            keep = fmaf(gx, gx, gy * gy) < (borders ? c.z : thr2);
+        }
+        const unsigned long long m = __ballot(keep);
+        const int pos = n + __popcll(m & ((1ull << lane) - 1ull));
+        n += __popcll(m);
+        if (n > GEO_CAND_MAX) return -1;                             // too many: caller falls back to all K
+        if (keep) list[pos] = k;
+    }
+    return n;
+}
+
 template <bool RAD>
-__global__ __launch_bounds__(BLOCK) void sfm_geometry_kernel(const TickArgs a) {
+__global__ __launch_bounds__(GEO_BLOCK) void sfm_geometry_kernel(const TickArgs a) {
+    __shared__ int s_list[3][GEO_CAND_MAX];
+    __shared__ int s_count[3];
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = uniform((int)(threadIdx.x >> 6));
-    const int i = a.i_begin + blockIdx.x * WAVES_PER_BLOCK + wave;
-    if (i >= a.i_end) return;
-    const float4 s = a.pk_cur[i];
-    const float x = uniform(s.x), y = uniform(s.y), vx = uniform(s.z), vy = uniform(s.w);
-    const float r = uniform(a.own[i].w);
-    float fbx = 0.f, fby = 0.f, fsx = 0.f, fsy = 0.f, fdx = 0.f, fdy = 0.f;
-    if (a.en_border && a.borders.K > 0 && !(a.crossing && a.crossing[i]))    // forces.py:140-141,176-177
-        border_force<RAD>(a, x, y, r, lane, fbx, fby);
-    if (a.en_static && a.statics.K > 0)
-        obstacle_force<RAD>(a.statics, a.stat, false, x, y, vx, vy, r, lane, fsx, fsy);
-    if (a.en_dynamic && a.dynamics.K > 0)
-        obstacle_force<RAD>(a.dynamics, a.dyn, true, x, y, vx, vy, r, lane, fdx, fdy);
-    if (lane < 6) {
-        const float v = lane == 0 ? fbx : lane == 1 ? fby : lane == 2 ? fsx : lane == 3 ? fsy : lane == 4 ? fdx : fdy;
-        a.geo[(size_t)lane * a.N_pad + i] = v;
+    const int t = (a.i_begin >> 6) + blockIdx.x;                      // tile index
+    const int p0 = max(a.i_begin, t * WAVE), p1 = min(a.i_end, (t + 1) * WAVE);
+    const bool want_b = a.en_border && a.borders.K > 0, want_s = a.en_static && a.statics.K > 0,
+               want_d = a.en_dynamic && a.dynamics.K > 0;
+    if (wave == 0) {
+        const int i = p0 + lane;
+        const float inf = __builtin_inff();
+        float x0 = inf, y0 = inf, x1 = -inf, y1 = -inf;
+        if (i < p1) { const float4 s = a.pk_cur[i]; x0 = x1 = s.x; y0 = y1 = s.y; }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            x0 = fminf(x0, __shfl_xor(x0, m)); y0 = fminf(y0, __shfl_xor(y0, m));
+            x1 = fmaxf(x1, __shfl_xor(x1, m)); y1 = fmaxf(y1, __shfl_xor(y1, m));
+        }
+        const int nb = want_b ? build_candidates(a.borders, true, 0.f, x0, y0, x1, y1, lane, s_list[0]) : 0;
+        const int ns = want_s ? build_candidates(a.statics, false, a.stat.thr2, x0, y0, x1, y1, lane, s_list[1]) : 0;
+        const int nd = want_d ? build_candidates(a.dynamics, false, a.dyn.thr2, x0, y0, x1, y1, lane, s_list[2]) : 0;
+        if (lane == 0) { s_count[0] = nb; s_count[1] = ns; s_count[2] = nd; }
+    }
+    __syncthreads();
+    const Cand cb{s_count[0] >= 0 ? s_list[0] : nullptr, s_count[0] >= 0 ? s_count[0] : a.borders.K};
+    const Cand cs{s_count[1] >= 0 ? s_list[1] : nullptr, s_count[1] >= 0 ? s_count[1] : a.statics.K};
+    const Cand cd{s_count[2] >= 0 ? s_list[2] : nullptr, s_count[2] >= 0 ? s_count[2] : a.dynamics.K};
+    for (int i = p0 + wave; i < p1; i += GEO_WAVES) {
+        const float4 s = a.pk_cur[i];
+        const float x = uniform(s.x), y = uniform(s.y), vx = uniform(s.z), vy = uniform(s.w);
+        const float r = uniform(a.own[i].w);
+        float fbx = 0.f, fby = 0.f, fsx = 0.f, fsy = 0.f, fdx = 0.f, fdy = 0.f;
+        if (want_b && cb.count > 0 && !(a.crossing && a.crossing[i]))    // forces.py:140-141,176-177
+            border_force<RAD>(a, cb, x, y, r, lane, fbx, fby);
+        if (want_s && cs.count > 0)
+            obstacle_force<RAD>(a.statics, cs, a.stat, false, x, y, vx, vy, r, lane, fsx, fsy);
+        if (want_d && cd.count > 0)
+            obstacle_force<RAD>(a.dynamics, cd, a.dyn, true, x, y, vx, vy, r, lane, fdx, fdy);
+        if (lane < 6) {
+            const float v = lane == 0 ? fbx : lane == 1 ? fby : lane == 2 ? fsx : lane == 3 ? fsy : lane == 4 ? fdx : fdy;
+            a.geo[(size_t)lane * a.N_pad + i] = v;
+        }
     }
 }
 
@@ -1033,9 +1099,9 @@ hipError_t launch_tick(int ipw, int team, bool z3, bool rad, const TickArgs& a, 
 hipError_t launch_geometry(bool rad, const TickArgs& a, hipStream_t st) {
     const int n_local = a.i_end - a.i_begin;
     if (n_local <= 0) return hipSuccess;
-    const int grid = (n_local + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
-    if (rad) hipLaunchKernelGGL((sfm_geometry_kernel<true>), dim3(grid), dim3(BLOCK), 0, st, a);
-    else hipLaunchKernelGGL((sfm_geometry_kernel<false>), dim3(grid), dim3(BLOCK), 0, st, a);
+    const int grid = ((a.i_end + WAVE - 1) >> 6) - (a.i_begin >> 6);      // tiles overlapping the shard
+    if (rad) hipLaunchKernelGGL((sfm_geometry_kernel<true>), dim3(grid), dim3(GEO_BLOCK), 0, st, a);
+    else hipLaunchKernelGGL((sfm_geometry_kernel<false>), dim3(grid), dim3(GEO_BLOCK), 0, st, a);
     return hipGetLastError();
 }
 
