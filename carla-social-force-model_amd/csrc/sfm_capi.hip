@@ -5,7 +5,9 @@
 #include "sfm_device.h"
 #include "sfm_hip.h"
 
+#include <algorithm>
 #include <cmath>
+#include <numeric>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -77,6 +79,12 @@ struct SfmHandle {
     int* work_count = nullptr;
     size_t work_cap = 0;
     int cut_mode = -1;                     // SFM_CUTOFF: 0 off, 1 on, -1 auto (N >= 8192)
+    // spatial reordering: row s holds the caller's pedestrian perm[s] (Morton order of 1 m cells), so the 64-tiles
+    // are compact squares; every download translates back.  Identity when off.
+    std::vector<uint32_t> perm;
+    uint32_t* ids = nullptr;
+    bool reordered = false;
+    int reorder_mode = -1;                 // SFM_REORDER: 0 off, 1 on, -1 auto (N >= 8192)
     float r_max = 0.f;
     bool used_sym = false;
 
@@ -182,6 +190,8 @@ int sfm_create(const SfmParams* params, int device_id, SfmHandle** out) {
     if (ov) h->sym_mode = atoi(ov);
     ov = getenv("SFM_CUTOFF");
     if (ov) h->cut_mode = atoi(ov);
+    ov = getenv("SFM_REORDER");
+    if (ov) h->reorder_mode = atoi(ov);
     h->dpp_dir = probe_dpp_direction(nullptr);
     *out = h;
     return SFM_OK;
@@ -211,6 +221,7 @@ int sfm_destroy(SfmHandle* h) {
     if (h->dyn_rot) hipFree(h->dyn_rot);
     if (h->slab) hipFree(h->slab);
     if (h->tile_flag) hipFree(h->tile_flag);
+    if (h->ids) hipFree(h->ids);
     if (h->tile_box) hipFree(h->tile_box);
     if (h->tile_vmax) hipFree(h->tile_vmax);
     if (h->work) hipFree(h->work);
@@ -383,6 +394,7 @@ int sfm_upload_state(SfmHandle* h, int N, const float* x, const float* y, const 
         HIP_TRY(h, dev_realloc(h->crossing, (size_t)n_pad));
         HIP_TRY(h, dev_realloc(h->arrived, (size_t)n_pad));
         HIP_TRY(h, dev_realloc(h->draws, (size_t)n_pad));
+        HIP_TRY(h, dev_realloc(h->ids, (size_t)n_pad));
         HIP_TRY(h, dev_realloc(h->rec, (size_t)n_pad * 18));
         HIP_TRY(h, dev_realloc(h->geo, (size_t)n_pad * 6));
         h->cap = n_pad;
@@ -397,12 +409,33 @@ int sfm_upload_state(SfmHandle* h, int N, const float* x, const float* y, const 
     std::vector<float2> zv((size_t)n_pad, make_float2(0.f, 0.f));
     std::vector<float> rr((size_t)n_pad, 0.f);
     std::vector<uint8_t> cm((size_t)n_pad, 0);
-    for (int i = 0; i < N; ++i) {
-        pk[i] = make_float4(x[i], y[i], vx[i], vy[i]);
-        own[i] = make_float4(wx[i], wy[i], target_speed[i], radius ? radius[i] : 0.f);
-        if (z3) zv[i] = make_float2(z[i], vz[i]);
-        if (radius) rr[i] = radius[i];
-        if (crossing_mask) cm[i] = crossing_mask[i] ? 1 : 0;
+    // spatial order: Morton code of the 1 m cell (ties by index, so the order is a pure function of the state)
+    h->reordered = (h->reorder_mode == 1 || (h->reorder_mode < 0 && N >= 8192));
+    h->perm.resize((size_t)N);
+    std::iota(h->perm.begin(), h->perm.end(), 0u);
+    if (h->reordered) {
+        float x0 = x[0], y0 = y[0];
+        for (int i = 1; i < N; ++i) { x0 = std::fmin(x0, x[i]); y0 = std::fmin(y0, y[i]); }
+        auto spread = [](uint32_t v) {          // 16 bits -> every other bit
+            v &= 0xffffu; v = (v | (v << 8)) & 0x00ff00ffu; v = (v | (v << 4)) & 0x0f0f0f0fu;
+            v = (v | (v << 2)) & 0x33333333u; v = (v | (v << 1)) & 0x55555555u; return v;
+        };
+        std::vector<uint32_t> key((size_t)N);
+        for (int i = 0; i < N; ++i) {
+            const float fx = x[i] - x0, fy = y[i] - y0;      // NaN / huge coordinates clamp to the last cell
+            const uint32_t cxq = (fx >= 0.f && fx < 65535.f) ? (uint32_t)fx : 65535u;
+            const uint32_t cyq = (fy >= 0.f && fy < 65535.f) ? (uint32_t)fy : 65535u;
+            key[i] = spread(cxq) | (spread(cyq) << 1);
+        }
+        std::stable_sort(h->perm.begin(), h->perm.end(), [&](uint32_t a_, uint32_t b_) { return key[a_] < key[b_]; });
+    }
+    for (int s_ = 0; s_ < N; ++s_) {
+        const int i = (int)h->perm[s_];
+        pk[s_] = make_float4(x[i], y[i], vx[i], vy[i]);
+        own[s_] = make_float4(wx[i], wy[i], target_speed[i], radius ? radius[i] : 0.f);
+        if (z3) zv[s_] = make_float2(z[i], vz[i]);
+        if (radius) rr[s_] = radius[i];
+        if (crossing_mask) cm[s_] = crossing_mask[i] ? 1 : 0;
     }
     for (int b = 0; b < 2; ++b) {
         HIP_TRY(h, hipMemcpy(h->pk[b], pk.data(), sizeof(float4) * (size_t)n_pad, hipMemcpyHostToDevice));
@@ -412,6 +445,7 @@ int sfm_upload_state(SfmHandle* h, int N, const float* x, const float* y, const 
     HIP_TRY(h, hipMemcpy(h->radius, rr.data(), sizeof(float) * (size_t)n_pad, hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->crossing, cm.data(), (size_t)n_pad, hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemset(h->draws, 0, sizeof(uint32_t) * (size_t)n_pad));
+    if (h->reordered) HIP_TRY(h, hipMemcpy(h->ids, h->perm.data(), sizeof(uint32_t) * (size_t)N, hipMemcpyHostToDevice));
     // slab of the symmetric path: n_t x (n_t*64) float2 (8.6 GB at N = 262 144), up to 16 GiB of the 288 GB
     h->n_t = (N + WAVE - 1) / WAVE;
     const size_t need = (size_t)h->n_t * (size_t)h->n_t * WAVE;
@@ -475,6 +509,7 @@ static void fill_args(SfmHandle* h, TickArgs& a, uint32_t flags) {
     a.radius = h->radius;
     a.crossing = h->crossing;
     a.draws = h->draws;
+    a.ids = h->reordered ? h->ids : nullptr;
     a.rec = (flags & SFM_TICK_RECORD_FORCES) ? h->rec : nullptr;
     a.N = h->N; a.N_pad = h->N_pad; a.i_begin = h->i_begin; a.i_end = h->i_end;
     const bool any_geo = (p.enabled[SFM_FORCE_BORDER] && h->borders.K > 0) || (p.enabled[SFM_FORCE_STATIC_OBSTACLE] && h->statics.K > 0) ||
@@ -609,10 +644,11 @@ int sfm_download_velocities(SfmHandle* h, float* vx, float* vy, float* vz) {
     std::vector<float2> zv;
     rc = fetch_packed(h, pk, zv, vz != nullptr);
     if (rc) return rc;
-    for (int i = h->i_begin; i < h->i_end; ++i) {
-        vx[i] = pk[i - h->i_begin].z;
-        vy[i] = pk[i - h->i_begin].w;
-        if (vz) vz[i] = h->z3 ? zv[i - h->i_begin].y : 0.f;
+    for (int s_ = h->i_begin; s_ < h->i_end; ++s_) {
+        const int i = (int)h->perm[s_];
+        vx[i] = pk[s_ - h->i_begin].z;
+        vy[i] = pk[s_ - h->i_begin].w;
+        if (vz) vz[i] = h->z3 ? zv[s_ - h->i_begin].y : 0.f;
     }
     return SFM_OK;
 }
@@ -631,8 +667,9 @@ int sfm_download_state(SfmHandle* h, float* x, float* y, float* z, float* vx, fl
         own.resize((size_t)n);
         HIP_TRY(h, hipMemcpy(own.data(), h->own + h->i_begin, sizeof(float4) * (size_t)n, hipMemcpyDeviceToHost));
     }
-    for (int i = h->i_begin; i < h->i_end; ++i) {
-        const int k = i - h->i_begin;
+    for (int s_ = h->i_begin; s_ < h->i_end; ++s_) {
+        const int k = s_ - h->i_begin;
+        const int i = (int)h->perm[s_];
         if (x) x[i] = pk[k].x;
         if (y) y[i] = pk[k].y;
         if (vx) vx[i] = pk[k].z;
@@ -656,10 +693,12 @@ int sfm_download_forces(SfmHandle* h, int which, float* fx, float* fy, float* fz
     const size_t n = (size_t)h->N;
     const int cnt = h->i_end - h->i_begin;
     float* dst[3] = {fx, fy, fz};
+    std::vector<float> tmp((size_t)cnt);
     for (int c = 0; c < 3; ++c) {
         if (!dst[c]) continue;
-        HIP_TRY(h, hipMemcpy(dst[c] + h->i_begin, h->rec + ((size_t)which * 3 + c) * n + h->i_begin,
+        HIP_TRY(h, hipMemcpy(tmp.data(), h->rec + ((size_t)which * 3 + c) * n + h->i_begin,
                              sizeof(float) * (size_t)cnt, hipMemcpyDeviceToHost));
+        for (int k = 0; k < cnt; ++k) dst[c][h->perm[(size_t)h->i_begin + k]] = tmp[k];
     }
     return SFM_OK;
 }
@@ -671,8 +710,10 @@ int sfm_get_arrived(SfmHandle* h, float threshold, uint8_t* mask) {
     if (!mask) return fail(h, SFM_ERR_INVALID, "mask is NULL");
     const float thr2 = (float)((double)threshold * (double)threshold);
     HIP_TRY(h, launch_arrived(h->pk[h->cur], h->own, h->N, thr2, h->arrived, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(mask, h->arrived, (size_t)h->N, hipMemcpyDeviceToHost, h->stream));
+    std::vector<uint8_t> tmp((size_t)h->N);
+    HIP_TRY(h, hipMemcpyAsync(tmp.data(), h->arrived, (size_t)h->N, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    for (int s_ = 0; s_ < h->N; ++s_) mask[h->perm[s_]] = tmp[s_];
     return SFM_OK;
 }
 
@@ -682,8 +723,10 @@ int sfm_download_draw_counts(SfmHandle* h, uint32_t* counts) {
     if (h->N == 0) return SFM_OK;
     if (!counts) return fail(h, SFM_ERR_INVALID, "counts is NULL");
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    HIP_TRY(h, hipMemcpy(counts + h->i_begin, h->draws + h->i_begin, sizeof(uint32_t) * (size_t)(h->i_end - h->i_begin),
-                         hipMemcpyDeviceToHost));
+    const int cnt = h->i_end - h->i_begin;
+    std::vector<uint32_t> tmp((size_t)cnt);
+    HIP_TRY(h, hipMemcpy(tmp.data(), h->draws + h->i_begin, sizeof(uint32_t) * (size_t)cnt, hipMemcpyDeviceToHost));
+    for (int k = 0; k < cnt; ++k) counts[h->perm[(size_t)h->i_begin + k]] = tmp[k];
     return SFM_OK;
 }
 

@@ -44,6 +44,7 @@ struct TickArgs {
     const float* radius;      // [N_pad] radius stream for the j side (use_ped_radius only)
     const uint8_t* crossing;  // border-force mask
     uint32_t* draws;          // waypoint draw counters
+    const uint32_t* ids;      // caller's index of the pedestrian in each row (spatial reordering); null = identity
     float* rec;               // optional per-force record, layout [6][3][N]
     float* geo;               // geometry forces of this tick, layout [6][N_pad]: {fbx,fby,fsx,fsy,fdx,fdy}; null = none
     int N, N_pad, i_begin, i_end;

@@ -702,8 +702,9 @@ __global__ __launch_bounds__(BLOCK) void sfm_tick_kernel(const TickArgs a) {
             if (fmaf(ax_, ax_, ay_ * ay_) < a.arrive_thr2) {
                 redraw = true;
                 nd = a.draws[i] + 1u;
-                wx = waypoint_coord(a.seed, (uint32_t)i, nd, 0u, a.world_side);
-                wy = waypoint_coord(a.seed, (uint32_t)i, nd, 1u, a.world_side);
+                const uint32_t pid = a.ids ? a.ids[i] : (uint32_t)i;     // the stream is keyed by the caller's index
+                wx = waypoint_coord(a.seed, pid, nd, 0u, a.world_side);
+                wy = waypoint_coord(a.seed, pid, nd, 1u, a.world_side);
             }
         }
         float nx = x, ny = y, nz = z;
@@ -1011,8 +1012,9 @@ __global__ __launch_bounds__(EPI_BLOCK) void sfm_sym_epilogue_kernel(const TickA
         const float ax_ = wx - x, ay_ = wy - y;
         if (fmaf(ax_, ax_, ay_ * ay_) < a.arrive_thr2) {
             const uint32_t nd = nd0 + 1u;
-            wx = waypoint_coord(a.seed, (uint32_t)i, nd, 0u, a.world_side);
-            wy = waypoint_coord(a.seed, (uint32_t)i, nd, 1u, a.world_side);
+            const uint32_t pid = a.ids ? a.ids[i] : (uint32_t)i;
+            wx = waypoint_coord(a.seed, pid, nd, 0u, a.world_side);
+            wy = waypoint_coord(a.seed, pid, nd, 1u, a.world_side);
             a.own[i] = make_float4(wx, wy, o.z, o.w);
             a.draws[i] = nd;
         }

@@ -130,9 +130,10 @@ class ShardedStepper:
         if self.world == 1:
             return loc, vel, wp
         import torch.distributed as dist
-        mine = np.concatenate([loc[self.lo:self.hi], vel[self.lo:self.hi], wp[self.lo:self.hi]], axis=1)
+        own = np.flatnonzero(~np.isnan(vel[:, 0]))          # this rank's pedestrians (rows are an internal order)
+        mine = np.concatenate([loc[own], vel[own], wp[own]], axis=1)
         parts = [None] * self.world
-        dist.all_gather_object(parts, (self.lo, self.hi, mine), group=self.group)
-        for lo, hi, blk in parts:
-            loc[lo:hi], vel[lo:hi], wp[lo:hi] = blk[:, 0:3], blk[:, 3:6], blk[:, 6:8]
+        dist.all_gather_object(parts, (own, mine), group=self.group)
+        for idx, blk in parts:
+            loc[idx], vel[idx], wp[idx] = blk[:, 0:3], blk[:, 3:6], blk[:, 6:8]
         return loc, vel, wp

@@ -309,6 +309,7 @@ def test_tile_cutoff_keeps_parity(order, sym, monkeypatch):
     grid index order has compact tiles (most pairs skipped at this size); the same crowd in scrambled order
     has overlapping boxes (nothing skipped).  Both must match the oracle, in both pair kernels."""
     monkeypatch.setenv("SFM_CUTOFF", "1")
+    monkeypatch.setenv("SFM_REORDER", "0")       # the cutoff on its own: rows stay in the caller's order
     monkeypatch.setenv("SFM_SYM", sym)
     n = 12000
     sc = scenarios.make_scenario(n, 515)
@@ -350,3 +351,38 @@ def test_tile_cutoff_keeps_parity(order, sym, monkeypatch):
             e2.close()
         if order == "grid":
             assert times["grid"] < 0.8 * times["scrambled"], times
+
+
+def test_spatial_reordering_is_invisible_to_the_caller(monkeypatch):
+    """Rows are Morton-sorted internally (sfm_upload_state, N >= 8192 or SFM_REORDER=1); every download must come
+    back at the caller's index, the waypoint stream must stay keyed by the caller's index, and a scrambled crowd
+    must give the same per-pedestrian results as the same crowd in grid order."""
+    n = 3000
+    sc = scenarios.make_scenario(n, 777, n_borders=8, n_static=4, border_len=(5.0, 20.0))
+    perm = np.random.default_rng(5).permutation(n)
+    cfg = default_sfm_config(("acceleration_force", "pedestrian_force", "border_force", "static_obstacle_force"))
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("SFM_REORDER", mode)
+        monkeypatch.setenv("SFM_CUTOFF", mode)
+        eng = SfmEngine(cfg, 0.05)
+        try:
+            eng.set_borders(sc.borders, sc.border_centers, sc.border_lengths)
+            eng.set_static_obstacles(sc.static_obstacles)
+            eng.upload_state(sc.loc[perm], sc.vel[perm], sc.waypoint[perm], sc.target_speed[perm], sc.radius[perm], None)
+            eng.set_waypoint_stream(sc.seed, sc.world_side, 2.0)
+            eng.tick(record=True)
+            F = eng.forces("total")
+            arrived = eng.arrived(2.0)
+            eng.run(40, redraw=True)
+            out[mode] = (F, arrived, *eng.state(), eng.draw_counts())
+        finally:
+            eng.close()
+    a, b = out["0"], out["1"]
+    scale = np.abs(a[0]).max()
+    assert np.max(np.abs(a[0] - b[0])) <= 2e-5 * scale                   # same forces, pedestrian by pedestrian
+    assert np.array_equal(a[1], b[1])
+    assert b[5].sum() > 0 and np.array_equal(a[5], b[5])                 # same pedestrians redrew
+    moved = a[5] > 0
+    assert np.allclose(a[4][moved], b[4][moved], atol=1e-4)              # ... to the same waypoints
+    assert np.median(np.linalg.norm(a[2] - b[2], axis=1)) < 1e-3         # trajectories agree (fp32 order effects only)

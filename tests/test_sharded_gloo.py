@@ -62,9 +62,11 @@ class OracleShardEngine:
 
     def state(self):
         v = self.buf.view(self.n_pad, 4).numpy()
-        loc = np.zeros((self.n, 3)); vel = np.zeros((self.n, 3))
-        loc[:, :2] = v[:self.n, 0:2]; vel[:, :2] = v[:self.n, 2:4]
-        return loc, vel, self.wp[:, :2].copy()
+        loc = np.full((self.n, 3), np.nan); vel = np.full((self.n, 3), np.nan); wp = np.full((self.n, 2), np.nan)
+        lo, hi = self.lo, self.hi                     # like the HIP engine: only this rank's pedestrians
+        loc[lo:hi, :2] = v[lo:hi, 0:2]; vel[lo:hi, :2] = v[lo:hi, 2:4]; loc[lo:hi, 2] = 0.0; vel[lo:hi, 2] = 0.0
+        wp[lo:hi] = self.wp[lo:hi, :2]
+        return loc, vel, wp
 
 
 CFG = default_sfm_config(("acceleration_force", "pedestrian_force", "border_force"))
