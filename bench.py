@@ -86,10 +86,10 @@ def cpu_baseline(sc, forces, cfg, budget_s=15.0):
     t_probe = time.perf_counter() - t0
     est_tick = t_probe * sc.n / probe
     if est_tick <= budget_s:
-        reps = max(1, int(budget_s / est_tick))
-        t0 = time.perf_counter()
-        for _ in range(reps):
+        reps, t0 = 0, time.perf_counter()
+        while reps == 0 or time.perf_counter() - t0 < budget_s:      # whole ticks until the budget is used
             c_oracle.tick(*args, nthreads=cores)
+            reps += 1
         dt = (time.perf_counter() - t0) / reps
         sample = f"{reps} full ticks of {len(forces)} forces at N={sc.n}"
     else:
@@ -167,13 +167,26 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # dominant kernel: HIP events on the launch stream around `reps` launches (no collective in between)
+    # whole tick on the launch stream (HIP events, no collective in between) ...
     reps = min(max(args.steps, 1), 200 if sc.n <= 16384 else 10)
     eng.engine.run(reps, redraw=True)
     ev_ms, ev_ticks, ev_launches = eng.engine.timing()
-    kernel_us = ev_ms * 1e3 / max(ev_launches, 1)
-    alg = algorithmic_bytes(sc, forces, hi - lo)
+    tick_us = ev_ms * 1e3 / max(ev_ticks, 1)
+    # ... and the dominant kernel (the pedestrian-pair kernel) on its own, same stream, HIP events
+    kernel_us = eng.engine.profile_dominant_kernel(reps)
+    variant = eng.engine.kernel_variant()
+    dominant = "sfm_pair_sym_kernel" if "sym" in variant else variant
+    alg = 16.0 * (hi - lo) * (sc.n - 1.0) if "pedestrian_force" in forces else 0.0
+    if "sym" not in variant:
+        alg += 44.0 * (hi - lo)                      # the ordered kernel also reads / writes the own rows
+    alg_tick = algorithmic_bytes(sc, forces, hi - lo)
     achieved = alg / (kernel_us * 1e-6) / 1e9
+    traffic = None
+    try:                                              # HBM-side bytes per launch from the committed PMC passes
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            traffic = json.load(f).get(name, {}).get(dominant, {}).get("hbm_bytes")
+    except (OSError, ValueError):
+        pass
     barrier()
 
     if rank == 0:
@@ -186,14 +199,17 @@ def main():
             "config": {"workload": f"{name}: N={n} pedestrians, forces={'+'.join(f.replace('_force', '') for f in forces)}, "
                                    f"borders={len(sc.borders)}, static={len(sc.static_obstacles)}, dynamic={len(sc.dynamic_obstacles)}, "
                                    f"dt={dt}", "n_pedestrians": n, "sharding": f"rows/{world}" + (", 1 all-gather/tick" if world > 1 else ""),
-                       "kernel": eng.engine.kernel_variant()},
+                       "kernel": variant},
             "ns_per_pair": elapsed / args.steps * 1e9 / (n * (n - 1.0)),
             "pairs_per_s": n * (n - 1.0) * ticks_s,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel_us": kernel_us, "algorithmic_bytes_per_launch": alg,
-                         "note": "algorithmic bytes (16 B per ordered pair ...) / HIP-event kernel time; the pair operand "
-                                 "stream is served from LDS/L2, the on-chip bound is VALU issue (DESIGN.md)"},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": dominant, "kernel_us": kernel_us, "algorithmic_bytes_per_launch": alg,
+                         "tick_us": tick_us, "launches_per_tick": ev_launches / max(ev_ticks, 1),
+                         "algorithmic_bytes_per_tick": alg_tick,
+                         "note": "dominant kernel = the pedestrian-pair kernel: 16 B per ordered pair x the pairs one launch "
+                                 "covers / its HIP-event time; traffic = HBM bytes per launch from rocprofv3 PMC passes "
+                                 "(profiles/). The operand stream is served on-chip; the binding resource is VALU issue (DESIGN.md 3.4)"},
         }
         if single_ref is not None:
             out["single_gpu_same_workload"] = {"value": single_ref, "unit": "ticks/s", "speedup": ticks_s / single_ref}

@@ -73,6 +73,7 @@ SYMBOLS = {
     "sfm_packed_z_ptr": (C.c_void_p, [_H]),
     "sfm_last_error": (C.c_char_p, [_H]),
     "sfm_get_timing": (C.c_int, [_H, C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "sfm_profile_dominant_kernel": (C.c_int, [_H, C.c_int, C.POINTER(C.c_float)]),
     "sfm_kernel_variant": (C.c_char_p, [_H]),
 }
 

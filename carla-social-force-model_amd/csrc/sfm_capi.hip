@@ -615,6 +615,37 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags) {
     return SFM_OK;
 }
 
+int sfm_profile_dominant_kernel(SfmHandle* h, int reps, float* avg_us) {
+    int rc = bind(h);
+    if (rc) return rc;
+    if (reps <= 0 || !avg_us) return fail(h, SFM_ERR_INVALID, "reps <= 0 or avg_us is NULL");
+    if (h->N == 0 || !h->pk[0]) return fail(h, SFM_ERR_STATE, "no state uploaded");
+    rc = run_ticks(h, 1, 0);                       // settles the launch shape (and the cutoff work list) ...
+    if (rc) return rc;
+    h->cur ^= 1;                                   // ... and steps back: the probe must not advance the state
+    const int n_local = h->i_end - h->i_begin;
+    int ipw = 1, team = 1;
+    pick_shape(h, n_local, &ipw, &team);
+    TickArgs a;
+    fill_args(h, a, 0);
+    if (h->used_sym) a.geo = nullptr;
+    SymArgs sa{h->slab, h->tile_flag, h->n_t, h->n_t * WAVE, h->dpp_dir, -1, a.tile_box ? h->work : nullptr,
+               a.tile_box ? h->work_count : nullptr};
+    if (a.tile_box) HIP_TRY(h, launch_tile_bounds(a.pk_cur, h->N, h->tile_box, h->tile_vmax, h->stream));
+    HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+    for (int r = 0; r < reps; ++r) {
+        if (h->used_sym) HIP_TRY(h, launch_sym_pair(a, sa, h->stream));
+        else if (n_local > 0) HIP_TRY(h, launch_tick(ipw, team, h->z3, h->rad, a, h->stream));
+    }
+    HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
+    HIP_TRY(h, hipEventSynchronize(h->ev1));
+    float ms = 0.f;
+    HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    *avg_us = ms * 1000.0f / (float)reps;
+    h->timing_valid = false;
+    return SFM_OK;
+}
+
 int sfm_tick(SfmHandle* h, uint32_t flags) { return run_ticks(h, 1, flags); }
 
 int sfm_run(SfmHandle* h, int ticks, uint32_t flags) { return run_ticks(h, ticks, flags | SFM_TICK_INTEGRATE); }

@@ -277,5 +277,11 @@ class SfmEngine:
         self._check(self._lib.sfm_get_timing(self._h, C.byref(ms), C.byref(t), C.byref(l)), "sfm_get_timing")
         return ms.value, t.value, l.value
 
+    def profile_dominant_kernel(self, reps=100):
+        """Average microseconds per launch of the pedestrian-pair kernel alone (HIP events, state not advanced)."""
+        us = C.c_float(0)
+        self._check(self._lib.sfm_profile_dominant_kernel(self._h, int(reps), C.byref(us)), "sfm_profile_dominant_kernel")
+        return us.value
+
     def kernel_variant(self):
         return self._lib.sfm_kernel_variant(self._h).decode()

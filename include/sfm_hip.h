@@ -169,6 +169,10 @@ const char* sfm_last_error(const SfmHandle* h);
 /* HIP-event time of the last sfm_tick / sfm_run on its stream: total ms, ticks it covered and kernel
  * launches it issued. */
 int sfm_get_timing(SfmHandle* h, float* elapsed_ms, int* ticks, int* launches);
+/* Times the DOMINANT kernel of a tick on its own: `reps` back-to-back launches of the pedestrian-pair kernel the
+ * current state would use (the symmetric tile-pair kernel, or the ordered fused tick kernel with flags = 0),
+ * bracketed by HIP events on the handle's stream.  The state is not advanced.  For roofline accounting. */
+int sfm_profile_dominant_kernel(SfmHandle* h, int reps, float* avg_us);
 /* Name of the pair kernel variant the last tick used (for profiles), static storage. */
 const char* sfm_kernel_variant(const SfmHandle* h);
 int sfm_abi_version(void);
