@@ -64,6 +64,7 @@ SYMBOLS = {
     "sfm_set_waypoint_stream": (C.c_int, [_H, C.c_uint32, C.c_float, C.c_float]),
     "sfm_tick": (C.c_int, [_H, C.c_uint32]),
     "sfm_run": (C.c_int, [_H, C.c_int, C.c_uint32]),
+    "sfm_run_recorded": (C.c_int, [_H, C.c_int, C.c_uint32, C.c_int, _F, C.c_int, C.POINTER(C.c_int)]),
     "sfm_download_velocities": (C.c_int, [_H, _F, _F, _F]),
     "sfm_download_state": (C.c_int, [_H, _F, _F, _F, _F, _F, _F, _F, _F]),
     "sfm_download_forces": (C.c_int, [_H, C.c_int, _F, _F, _F]),

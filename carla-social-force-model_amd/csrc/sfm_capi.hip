@@ -650,6 +650,45 @@ int sfm_tick(SfmHandle* h, uint32_t flags) { return run_ticks(h, 1, flags); }
 
 int sfm_run(SfmHandle* h, int ticks, uint32_t flags) { return run_ticks(h, ticks, flags | SFM_TICK_INTEGRATE); }
 
+int sfm_run_recorded(SfmHandle* h, int ticks, uint32_t flags, int stride, float* frames, int max_frames, int* n_frames) {
+    int rc = bind(h);
+    if (rc) return rc;
+    if (ticks < 0 || stride <= 0 || max_frames < 0 || (!frames && max_frames > 0) || !n_frames)
+        return fail(h, SFM_ERR_INVALID, "bad recording arguments");
+    *n_frames = 0;
+    if (h->N == 0 || ticks == 0) return SFM_OK;
+    if (!h->pk[0]) return fail(h, SFM_ERR_STATE, "sfm_upload_state has not been called");
+    const int want = std::min(max_frames, (ticks + stride - 1) / stride);
+    const size_t frame_recs = (size_t)h->N;
+    float4* stage = nullptr;                                   // pinned, rows in the library's order
+    if (want > 0) HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&stage), sizeof(float4) * frame_recs * (size_t)want, 0));
+    int done = 0, f = 0;
+    while (done < ticks && rc == SFM_OK) {
+        if (f < want) {
+            hipError_t e = hipMemcpyAsync(stage + frame_recs * (size_t)f, h->pk[h->cur], sizeof(float4) * frame_recs,
+                                          hipMemcpyDeviceToHost, h->stream);
+            if (e != hipSuccess) { h->err = std::string("hipMemcpyAsync: ") + hipGetErrorString(e); rc = SFM_ERR_HIP; break; }
+            ++f;
+        }
+        const int chunk = std::min(stride, ticks - done);
+        rc = run_ticks(h, chunk, flags | SFM_TICK_INTEGRATE);
+        done += chunk;
+    }
+    if (rc == SFM_OK && hipStreamSynchronize(h->stream) != hipSuccess) rc = fail(h, SFM_ERR_HIP, "hipStreamSynchronize failed");
+    if (rc == SFM_OK) {
+        for (int k = 0; k < f; ++k)
+            for (int s_ = 0; s_ < h->N; ++s_) {
+                const float4 v = stage[frame_recs * (size_t)k + s_];
+                float* dst = frames + ((size_t)k * h->N + h->perm[s_]) * 4;
+                dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+            }
+        *n_frames = f;
+    }
+    if (stage) hipHostFree(stage);
+    h->timing_valid = false;
+    return rc;
+}
+
 // ---- downloads ------------------------------------------------------------------------------------
 
 static int fetch_packed(SfmHandle* h, std::vector<float4>& pk, std::vector<float2>& zv, bool want_z) {

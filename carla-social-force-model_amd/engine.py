@@ -224,6 +224,17 @@ class SfmEngine:
     def run(self, ticks, redraw=False, record=False):
         self._check(self._lib.sfm_run(self._h, int(ticks), self._flags(True, redraw, record)), "sfm_run")
 
+    def run_recorded(self, ticks, stride=1, redraw=False):
+        """``run`` that records {x, y, vx, vy} of every pedestrian before tick 0, stride, 2*stride, ...
+        Returns (frames[F, N, 4] float32, tick_index[F])."""
+        n_frames = (int(ticks) + int(stride) - 1) // int(stride) if ticks > 0 else 0
+        frames = np.zeros((n_frames, self.n, 4), dtype=np.float32)
+        got = C.c_int(0)
+        self._check(self._lib.sfm_run_recorded(self._h, int(ticks), self._flags(True, redraw, False), int(stride),
+                                               fptr(frames.reshape(-1)) if frames.size else None, n_frames, C.byref(got)),
+                    "sfm_run_recorded")
+        return frames[:got.value], np.arange(got.value) * int(stride)
+
     # ---- results ----------------------------------------------------------------------------------
     def velocities(self):
         """(N,3) float64; rows outside this handle's shard are NaN."""

@@ -138,6 +138,13 @@ int sfm_tick(SfmHandle* h, uint32_t flags);
  * CARLA-free harness); flags as above, SFM_TICK_INTEGRATE is implied. */
 int sfm_run(SfmHandle* h, int ticks, uint32_t flags);
 
+/* sfm_run that also records the trajectory (replaces the per-tick full-state Python
+ * copy of PedState.record_current_state, pedestrian_state.py:100-104): frame f holds {x, y, vx, vy} of every
+ * pedestrian (caller's index order) BEFORE tick f*stride, like the reference records before computing forces
+ * (pedestrian_simulation.py:76).  frames: [max_frames][N][4] floats; *n_frames receives ceil(ticks/stride)
+ * (clamped to max_frames).  Copies are asynchronous device->pinned-host between the ticks. */
+int sfm_run_recorded(SfmHandle* h, int ticks, uint32_t flags, int stride, float* frames, int max_frames, int* n_frames);
+
 /* ---- results --------------------------------------------------------------------------------------- */
 
 /* get_new_velocities (pedestrian_simulation.py:126-127): v' of this handle's shard rows, written at

@@ -76,4 +76,4 @@ class Case:
 
 
 def list_cases():
-    return sorted(os.path.join(GOLDEN_DIR, f) for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz"))
+    return sorted(os.path.join(GOLDEN_DIR, f) for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and f != "csv_case.npz")

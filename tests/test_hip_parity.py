@@ -386,3 +386,31 @@ def test_spatial_reordering_is_invisible_to_the_caller(monkeypatch):
     moved = a[5] > 0
     assert np.allclose(a[4][moved], b[4][moved], atol=1e-4)              # ... to the same waypoints
     assert np.median(np.linalg.norm(a[2] - b[2], axis=1)) < 1e-3         # trajectories agree (fp32 order effects only)
+
+
+@pytest.mark.parametrize("n", [500, 9000])
+def test_recorded_run_matches_stepwise_downloads(n):
+    """sfm_run_recorded: frame f is the state before tick f*stride, in the caller's index order (also when the
+    rows are Morton-sorted internally, n = 9000), and recording does not perturb the run."""
+    sc = scenarios.make_scenario(n, 12, n_borders=4, border_len=(5.0, 20.0))
+    cfg = default_sfm_config(("acceleration_force", "pedestrian_force", "border_force"))
+    engs = []
+    for _ in range(2):
+        e = SfmEngine(cfg, 0.05)
+        e.set_borders(sc.borders, sc.border_centers, sc.border_lengths)
+        e.upload_state(sc.loc, sc.vel, sc.waypoint, sc.target_speed, sc.radius, None)
+        e.set_waypoint_stream(sc.seed, sc.world_side, 2.0)
+        engs.append(e)
+    try:
+        frames, ticks = engs[0].run_recorded(9, stride=4, redraw=True)
+        assert frames.shape == (3, n, 4) and list(ticks) == [0, 4, 8]
+        for f, k in enumerate(ticks):
+            loc, vel, _ = engs[1].state()
+            assert np.array_equal(frames[f, :, 0:2], loc[:, :2].astype(np.float32)), f"frame {f}"
+            assert np.array_equal(frames[f, :, 2:4], vel[:, :2].astype(np.float32)), f"frame {f}"
+            engs[1].run(min(4, 9 - k), redraw=True)
+        a, b = engs[0].state(), engs[1].state()
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    finally:
+        for e in engs:
+            e.close()
