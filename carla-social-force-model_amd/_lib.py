@@ -62,6 +62,8 @@ SYMBOLS = {
     "sfm_upload_state": (C.c_int, [_H, C.c_int, _F, _F, _F, _F, _F, _F, _F, _F, _F, _F, _U8]),
     "sfm_set_shard": (C.c_int, [_H, C.c_int, C.c_int]),
     "sfm_set_waypoint_stream": (C.c_int, [_H, C.c_uint32, C.c_float, C.c_float]),
+    "sfm_set_mode_fsm": (C.c_int, [_H, C.c_int, _U8, _F, _F, _F, _F, _F, _I, _F, _F, _U8, C.c_int, C.c_float, _F]),
+    "sfm_download_modes": (C.c_int, [_H, _U8, _F, _I]),
     "sfm_tick": (C.c_int, [_H, C.c_uint32]),
     "sfm_run": (C.c_int, [_H, C.c_int, C.c_uint32]),
     "sfm_run_recorded": (C.c_int, [_H, C.c_int, C.c_uint32, C.c_int, _F, C.c_int, C.POINTER(C.c_int)]),

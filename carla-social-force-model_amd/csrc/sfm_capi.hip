@@ -20,6 +20,7 @@ hipError_t launch_arrived(const float4* pk, const float4* own, int N, float thr2
 hipError_t launch_sym_pair(const TickArgs& a, const SymArgs& sa, hipStream_t st);
 hipError_t launch_sym_epilogue(const TickArgs& a, const SymArgs& sa, hipStream_t st);
 hipError_t launch_geometry(bool rad, const TickArgs& a, hipStream_t st);
+hipError_t launch_modes(const TickArgs& a, hipStream_t st);
 hipError_t launch_tile_bounds(const float4* pk, int N, float4* box, float* vmax, hipStream_t st);
 int probe_dpp_direction(hipStream_t st);
 hipError_t launch_dynamic_boxes(float4* ctr, const int* off, const float2* local, const float2* rot, float2* pts, int M,
@@ -90,6 +91,17 @@ struct SfmHandle {
 
     uint32_t seed = 0;
     float world_side = 0.f, arrive_thr = 2.0f;
+
+    // device-side mode FSM + waypoint queues (caller's index space)
+    bool fsm_on = false;
+    int fsm_n = 0;
+    uint8_t* f_mode = nullptr;
+    float *f_target = nullptr, *f_initial = nullptr, *f_crossing = nullptr, *f_margin = nullptr, *f_next = nullptr;
+    int *f_off = nullptr, *f_cursor = nullptr;
+    float2* f_xy = nullptr;
+    uint8_t* f_cross = nullptr;
+    float sim_time = 0.f, veh_ext[2] = {0.f, 0.f};
+    int despawn = 0;
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // geometry forces run on a side stream beside the pair kernel (they only need the tick's input state)
@@ -221,6 +233,9 @@ int sfm_destroy(SfmHandle* h) {
     if (h->dyn_rot) hipFree(h->dyn_rot);
     if (h->slab) hipFree(h->slab);
     if (h->tile_flag) hipFree(h->tile_flag);
+    for (void* q : {(void*)h->f_mode, (void*)h->f_target, (void*)h->f_initial, (void*)h->f_crossing, (void*)h->f_margin,
+                    (void*)h->f_next, (void*)h->f_off, (void*)h->f_cursor, (void*)h->f_xy, (void*)h->f_cross})
+        if (q) hipFree(q);
     if (h->ids) hipFree(h->ids);
     if (h->tile_box) hipFree(h->tile_box);
     if (h->tile_vmax) hipFree(h->tile_vmax);
@@ -401,6 +416,7 @@ int sfm_upload_state(SfmHandle* h, int N, const float* x, const float* y, const 
     }
     h->N = N; h->N_pad = n_pad; h->z3 = z3; h->rad = rad;
     h->i_begin = 0; h->i_end = N; h->cur = 0; h->rec_valid = false; h->timing_valid = false;
+    h->fsm_on = false;                     // a new crowd: the caller sets the FSM again if it wants it
     if (N == 0) return SFM_OK;
     std::vector<float4> pk((size_t)n_pad), own((size_t)n_pad, make_float4(0.f, 0.f, 0.f, 0.f));
     // padding rows are ghost pedestrians parked far away at distinct positions: every interaction with them
@@ -467,6 +483,64 @@ int sfm_upload_state(SfmHandle* h, int N, const float* x, const float* y, const 
     return SFM_OK;
 }
 
+int sfm_set_mode_fsm(SfmHandle* h, int N, const uint8_t* mode, const float* target_speed, const float* initial_speed,
+                     const float* crossing_speed, const float* safety_margin, const float* next_mode_time,
+                     const int32_t* wp_offsets, const float* wp_x, const float* wp_y, const uint8_t* wp_crossing,
+                     int despawn_on_arrival, float sim_time0, const float* first_vehicle_extent) {
+    int rc = bind(h);
+    if (rc) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (N == 0) { h->fsm_on = false; return SFM_OK; }
+    if (N != h->N) return fail(h, SFM_ERR_STATE, "sfm_set_mode_fsm: N differs from the uploaded state");
+    if (!mode || !target_speed || !initial_speed || !crossing_speed || !safety_margin || !next_mode_time || !wp_offsets)
+        return fail(h, SFM_ERR_INVALID, "a required FSM array is NULL");
+    if (wp_offsets[0] != 0) return fail(h, SFM_ERR_INVALID, "wp_offsets[0] must be 0");
+    for (int i = 0; i < N; ++i) {
+        if (wp_offsets[i + 1] < wp_offsets[i]) return fail(h, SFM_ERR_INVALID, "wp_offsets must be non-decreasing");
+        if (mode[i] > 4) return fail(h, SFM_ERR_INVALID, "mode must be a PedMode value 0..4");
+    }
+    const int W = wp_offsets[N];
+    if (W > 0 && (!wp_x || !wp_y || !wp_crossing)) return fail(h, SFM_ERR_INVALID, "waypoint arrays are NULL");
+    std::vector<float2> xy((size_t)(W > 0 ? W : 1));
+    for (int e = 0; e < W; ++e) xy[e] = make_float2(wp_x[e], wp_y[e]);
+    const size_t n = (size_t)N;
+    HIP_TRY(h, dev_realloc(h->f_mode, n)); HIP_TRY(h, dev_realloc(h->f_target, n)); HIP_TRY(h, dev_realloc(h->f_initial, n));
+    HIP_TRY(h, dev_realloc(h->f_crossing, n)); HIP_TRY(h, dev_realloc(h->f_margin, n)); HIP_TRY(h, dev_realloc(h->f_next, n));
+    HIP_TRY(h, dev_realloc(h->f_off, n + 1)); HIP_TRY(h, dev_realloc(h->f_cursor, n));
+    HIP_TRY(h, dev_realloc(h->f_xy, xy.size())); HIP_TRY(h, dev_realloc(h->f_cross, xy.size()));
+    HIP_TRY(h, hipMemcpy(h->f_mode, mode, n, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->f_target, target_speed, 4 * n, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->f_initial, initial_speed, 4 * n, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->f_crossing, crossing_speed, 4 * n, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->f_margin, safety_margin, 4 * n, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->f_next, next_mode_time, 4 * n, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->f_off, wp_offsets, 4 * (n + 1), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemset(h->f_cursor, 0, 4 * n));
+    if (W > 0) {
+        HIP_TRY(h, hipMemcpy(h->f_xy, xy.data(), sizeof(float2) * (size_t)W, hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(h->f_cross, wp_crossing, (size_t)W, hipMemcpyHostToDevice));
+    }
+    h->fsm_n = N;
+    h->despawn = despawn_on_arrival ? 1 : 0;
+    h->sim_time = sim_time0;
+    h->veh_ext[0] = first_vehicle_extent ? first_vehicle_extent[0] : 0.f;
+    h->veh_ext[1] = first_vehicle_extent ? first_vehicle_extent[1] : 0.f;
+    h->fsm_on = true;
+    return SFM_OK;
+}
+
+int sfm_download_modes(SfmHandle* h, uint8_t* mode, float* target_speed, int32_t* cursor) {
+    int rc = bind(h);
+    if (rc) return rc;
+    if (!h->fsm_on) return fail(h, SFM_ERR_STATE, "sfm_set_mode_fsm has not been called");
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const size_t n = (size_t)h->fsm_n;
+    if (mode) HIP_TRY(h, hipMemcpy(mode, h->f_mode, n, hipMemcpyDeviceToHost));
+    if (target_speed) HIP_TRY(h, hipMemcpy(target_speed, h->f_target, 4 * n, hipMemcpyDeviceToHost));
+    if (cursor) HIP_TRY(h, hipMemcpy(cursor, h->f_cursor, 4 * n, hipMemcpyDeviceToHost));
+    return SFM_OK;
+}
+
 int sfm_set_shard(SfmHandle* h, int i_begin, int i_end) {
     if (!h) return SFM_ERR_INVALID;
     if (i_begin < 0 || i_end < i_begin || i_end > h->N) return fail(h, SFM_ERR_INVALID, "shard out of range");
@@ -521,6 +595,9 @@ static void fill_args(SfmHandle* h, TickArgs& a, uint32_t flags) {
     a.tile_vmax = cut ? h->tile_vmax : nullptr;
     a.cut_scale = (float)((double)p.pedestrian.gamma * 41.0 * 0.6931471805599453 * 1.001);
     a.cut_pad = h->rad ? 2.0f * h->r_max * 1.001f : 0.f;
+    if (h->fsm_on)
+        a.fsm = FsmArgs{h->f_mode, h->f_target, h->f_initial, h->f_crossing, h->f_margin, h->f_next, h->f_off, h->f_xy, h->f_cross,
+                        h->f_cursor, h->sim_time, h->veh_ext[0], h->veh_ext[1], h->despawn};
     a.flags = flags;
     a.en_acc = p.enabled[SFM_FORCE_ACCELERATION];
     a.en_ped = p.enabled[SFM_FORCE_PEDESTRIAN];
@@ -572,6 +649,10 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags) {
         // border / obstacle forces only need the tick's input state.  With the symmetric path they run on the
         // side stream BESIDE the pair kernel (memory-latency-bound next to VALU-bound) and join before the
         // epilogue; the ordered kernel consumes them itself, so there they simply run first.
+        if (h->fsm_on && n_local > 0) {           // modes first: target speeds and the border mask feed the forces
+            HIP_TRY(h, launch_modes(a, h->stream));
+            ++launches;
+        }
         if (a.tile_box) {                         // boxes / speeds of this tick's input state (all tiles)
             HIP_TRY(h, launch_tile_bounds(a.pk_cur, h->N, h->tile_box, h->tile_vmax, h->stream));
             ++launches;
@@ -600,6 +681,7 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags) {
             ++launches;
         }
         h->cur ^= 1;
+        if (h->fsm_on) h->sim_time += h->prm.step_length;
         // CARLA-free runs: the vehicles move between ticks (run_simulation.py:77-95)
         if (h->dyn_boxes && (flags & SFM_TICK_INTEGRATE) && h->dynamics.K > 0) {
             HIP_TRY(h, launch_dynamic_boxes(h->dynamics.ctr, h->dynamics.off, h->dyn_local, h->dyn_rot, h->dynamics.pts,

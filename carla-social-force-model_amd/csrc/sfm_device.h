@@ -34,6 +34,27 @@ struct Geo {                  // CSR polylines / rings
     int K;
 };
 
+// Device-side pedestrian mode state machine + waypoint queues: the host loop of
+// ped_mode_manager.py:30-70, pedestrian_state.py:83-95, pedestrian_simulation.py:63-73 and
+// run_simulation.py:118-132 for device-resident runs.  mode == null: off.
+constexpr uint8_t MODE_IDLE = 0, MODE_WALKING = 1, MODE_CROSSING = 2, MODE_ROAD_TO_SIDEWALK = 3, MODE_CHECKING = 4,
+                  MODE_DESPAWNED = 255;
+struct FsmArgs {
+    uint8_t* mode;            // PedMode per pedestrian (MODE_DESPAWNED once removed)
+    float* target;            // the mode object's target_speed (applied to the state one tick later, like the reference)
+    const float* initial_speed;
+    const float* crossing_speed;
+    const float* safety_margin;
+    const float* next_mode_time;
+    const int* wp_off;        // [N+1] CSR of the remaining-waypoint lists (waypoint_dict, run_simulation.py:120-126)
+    const float2* wp_xy;
+    const uint8_t* wp_cross;  // 1: the leg towards this waypoint crosses a road
+    int* cursor;              // next unused entry of each list
+    float sim_time;
+    float veh_ext_x, veh_ext_y;   // extent of the FIRST vehicle (check_traffic.py:35-36 offsets every vehicle by it)
+    int despawn_on_arrival;
+};
+
 struct TickArgs {
     // packed j-operand state, N_pad records (padding rows are never selected)
     const float4* pk_cur;     // {x, y, vx, vy}
@@ -42,7 +63,7 @@ struct TickArgs {
     float2* zv_next;
     float4* own;              // {wx, wy, target_speed, radius}
     const float* radius;      // [N_pad] radius stream for the j side (use_ped_radius only)
-    const uint8_t* crossing;  // border-force mask
+    uint8_t* crossing;        // border-force mask (rewritten every tick by sfm_mode_kernel when the FSM is on)
     uint32_t* draws;          // waypoint draw counters
     const uint32_t* ids;      // caller's index of the pedestrian in each row (spatial reordering); null = identity
     float* rec;               // optional per-force record, layout [6][3][N]
@@ -64,6 +85,7 @@ struct TickArgs {
     const float* tile_vmax;   // [n_t] largest speed in the tile
     float cut_scale;          // gamma * 41 ln 2 (with margin): distance per unit of (lambda*(va+vb)+1)
     float cut_pad;            // 2 * largest radius when use_ped_radius, else 0
+    FsmArgs fsm;
 };
 
 // Symmetric (antisymmetry-exploiting) pedestrian-force path, single shard only.

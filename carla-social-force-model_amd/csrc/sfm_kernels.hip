@@ -444,6 +444,130 @@ __global__ __launch_bounds__(GEO_BLOCK) void sfm_geometry_kernel(const TickArgs 
 }
 
 // ------------------------------------------------------------------------------------------------------
+// pedestrian modes, waypoint queues and gap acceptance on the device
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float2 park_position(uint32_t pid) {      // where a despawned pedestrian waits: a ghost
+    return make_float2(3.0e15f + 1.0e12f * (float)(pid + 1u), -3.0e15f);
+}
+
+// PedModeManager._activate_mode (ped_mode_manager.py:49-70): entry action of `m`; returns the new target speed.
+__device__ __forceinline__ float fsm_enter(uint8_t m, float target, float initial, float crossing) {
+    if (m == MODE_IDLE || m == MODE_CHECKING) return 0.0f;
+    if (m == MODE_WALKING) return initial;
+    if (m == MODE_CROSSING) return crossing;
+    return target;                                                    // ROAD_TO_SIDEWALK keeps the speed
+}
+// PedModeManager.set_mode (ped_mode_manager.py:37-47): two requests are diverted through an intermediate mode.
+__device__ __forceinline__ uint8_t fsm_request(uint8_t cur, uint8_t want) {
+    if (cur == MODE_WALKING && want == MODE_CROSSING) return MODE_CHECKING;
+    if (cur == MODE_CROSSING && want == MODE_WALKING) return MODE_ROAD_TO_SIDEWALK;
+    return want;
+}
+
+// Distance from p to the segment a-b (shapely LineString.distance(Point)).
+__device__ __forceinline__ float seg_dist(float2 a, float2 b, float2 p) {
+    const float abx = b.x - a.x, aby = b.y - a.y;
+    const float ab2 = fmaf(abx, abx, aby * aby);
+    float t = ab2 > 0.0f ? (fmaf(p.x - a.x, abx, (p.y - a.y) * aby) / ab2) : 0.0f;
+    t = fminf(fmaxf(t, 0.0f), 1.0f);
+    const float qx = fmaf(t, abx, a.x) - p.x, qy = fmaf(t, aby, a.y) - p.y;
+    return sqrtf(fmaf(qx, qx, qy * qy));
+}
+
+// check_traffic (check_traffic.py:7-61) in closed form: does any vehicle's extrapolated path cross the
+// pedestrian's path while the pedestrian would be there?  true = safe to cross.
+__device__ bool gap_accepted(const TickArgs& a, float2 loc, float2 goal, float ped_speed, float margin) {
+    if (margin < 0.0f) return true;                                   // crosses without looking (:24)
+    if (!(ped_speed > 0.0f)) return true;
+    const float rx = goal.x - loc.x, ry = goal.y - loc.y;
+    const float time_ped = sqrtf(fmaf(rx, rx, ry * ry)) / ped_speed;
+    const float rr = fmaf(rx, rx, ry * ry);
+    for (int k = 0; k < a.dynamics.K; ++k) {
+        const float4 c = a.dynamics.ctr[k];                           // {cx, cy, vx, vy}
+        const float sp = sqrtf(fmaf(c.z, c.z, c.w * c.w));
+        const float inv = sp == 0.0f ? 1.0f : 1.0f / sp;
+        // (sic) every vehicle is offset by the FIRST vehicle's extent, element-wise (check_traffic.py:35-36)
+        const float ox = c.z * inv * a.fsm.veh_ext_x, oy = c.w * inv * a.fsm.veh_ext_y;
+        const float2 front = make_float2(c.x + ox, c.y + oy), back = make_float2(c.x - ox, c.y - oy);
+        const float T = time_ped + margin;
+        const float2 vgoal = make_float2(fmaf(c.z, T, front.x), fmaf(c.w, T, front.y));
+        // segment loc-goal (p0 + t r) against back-vgoal (q0 + u s)
+        const float sx = vgoal.x - back.x, sy = vgoal.y - back.y;
+        const float qpx = back.x - loc.x, qpy = back.y - loc.y;
+        const float rxs = rx * sy - ry * sx, qpxr = qpx * ry - qpy * rx;
+        bool hit = false, is_seg = false;
+        float2 h0 = make_float2(0.f, 0.f), h1 = h0;
+        if (rxs != 0.0f) {
+            const float t = (qpx * sy - qpy * sx) / rxs, u = qpxr / rxs;
+            if (t >= 0.0f && t <= 1.0f && u >= 0.0f && u <= 1.0f) { hit = true; h0 = make_float2(fmaf(t, rx, loc.x), fmaf(t, ry, loc.y)); }
+        } else if (qpxr == 0.0f && rr > 0.0f) {                       // collinear: overlap interval on the pedestrian's segment
+            const float t0 = fmaf(qpx, rx, qpy * ry) / rr, t1 = t0 + fmaf(sx, rx, sy * ry) / rr;
+            const float lo = fmaxf(0.0f, fminf(t0, t1)), hi = fminf(1.0f, fmaxf(t0, t1));
+            if (lo <= hi) {
+                hit = true; is_seg = lo < hi;
+                h0 = make_float2(fmaf(lo, rx, loc.x), fmaf(lo, ry, loc.y));
+                h1 = make_float2(fmaf(hi, rx, loc.x), fmaf(hi, ry, loc.y));
+            }
+        }
+        if (!hit || sp == 0.0f) continue;
+        if (!is_seg) h1 = h0;
+        const float tti_ped = seg_dist(h0, h1, loc) / ped_speed;
+        const float tti_front = seg_dist(h0, h1, front) / sp, tti_back = seg_dist(h0, h1, back) / sp;
+        if (tti_front - margin < tti_ped && tti_ped < tti_back + margin) return false;
+    }
+    return true;
+}
+
+// Start of PedestrianSimulation.tick (pedestrian_simulation.py:63-73): apply_current_mode, the FSM tick, gap
+// acceptance for the pedestrians waiting at the kerb.  One thread per row; FSM arrays are in the caller's index.
+__global__ void sfm_mode_kernel(const TickArgs a) {
+    const int i = a.i_begin + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.i_end) return;
+    const uint32_t pid = a.ids ? a.ids[i] : (uint32_t)i;
+    uint8_t m = a.fsm.mode[pid];
+    float4 o = a.own[i];
+    if (m == MODE_DESPAWNED) { o.z = 0.0f; a.own[i] = o; return; }
+    float tgt = a.fsm.target[pid];
+    o.z = tgt;                                                        // apply_current_mode (pedestrian_state.py:94-95)
+    if (m == MODE_IDLE && a.fsm.next_mode_time[pid] <= a.fsm.sim_time) {   // ped_mode_manager.py:30-35
+        m = MODE_WALKING;
+        tgt = a.fsm.initial_speed[pid];
+    }
+    if (m == MODE_CHECKING) {                                         // pedestrian_simulation.py:67-73
+        const float4 s = a.pk_cur[i];
+        const bool ready = a.dynamics.K == 0 ||
+                           gap_accepted(a, make_float2(s.x, s.y), make_float2(o.x, o.y), a.fsm.crossing_speed[pid],
+                                        a.fsm.safety_margin[pid]);
+        if (ready) { m = MODE_CROSSING; tgt = a.fsm.crossing_speed[pid]; }
+    }
+    a.fsm.mode[pid] = m;
+    a.fsm.target[pid] = tgt;
+    a.own[i] = o;
+    a.crossing[i] = (m == MODE_CROSSING || m == MODE_ROAD_TO_SIDEWALK) ? 1 : 0;   // forces.py:176-177
+}
+
+// run_simulation.py:118-132 for one arrived pedestrian: next waypoint from its list (and the mode request that
+// comes with it, pedestrian_state.py:83-92), or despawn when the list is exhausted.
+__device__ __forceinline__ void fsm_arrived(const TickArgs& a, uint32_t pid, float& wx, float& wy, bool& wp_changed,
+                                            bool& despawn) {
+    const int c = a.fsm.cursor[pid];
+    if (c < a.fsm.wp_off[pid + 1] - a.fsm.wp_off[pid]) {
+        const int e = a.fsm.wp_off[pid] + c;
+        const float2 w = a.fsm.wp_xy[e];
+        wx = w.x; wy = w.y; wp_changed = true;
+        a.fsm.cursor[pid] = c + 1;
+        const uint8_t cur = a.fsm.mode[pid];
+        const uint8_t nm = fsm_request(cur, a.fsm.wp_cross[e] ? MODE_CROSSING : MODE_WALKING);
+        a.fsm.target[pid] = fsm_enter(nm, a.fsm.target[pid], a.fsm.initial_speed[pid], a.fsm.crossing_speed[pid]);
+        a.fsm.mode[pid] = nm;
+    } else if (a.fsm.despawn_on_arrival) {
+        despawn = true;
+        a.fsm.mode[pid] = MODE_DESPAWNED;
+        a.fsm.target[pid] = 0.0f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
 // the fused tick
 // ------------------------------------------------------------------------------------------------------
 // TEAM = number of waves that share the same IPW pedestrians:
@@ -696,24 +820,35 @@ __global__ __launch_bounds__(BLOCK) void sfm_tick_kernel(const TickArgs a) {
 
         // arrival on the pre-move position -> next waypoint (pedestrian_simulation.py:92-95, run_simulation.py:118-126)
         uint32_t nd = 0;
-        bool redraw = false;
-        if (a.flags & 2u) {
+        bool redraw = false, despawn = false;
+        const uint32_t pid = a.ids ? a.ids[i] : (uint32_t)i;             // queues / streams are keyed by the caller's index
+        const bool gone = a.fsm.mode && a.fsm.mode[pid] == MODE_DESPAWNED;
+        {
             const float ax_ = wx - x, ay_ = wy - y;
-            if (fmaf(ax_, ax_, ay_ * ay_) < a.arrive_thr2) {
+            const bool here = fmaf(ax_, ax_, ay_ * ay_) < a.arrive_thr2;
+            if (a.fsm.mode) {
+                if (here && !gone && lane == 0) fsm_arrived(a, pid, wx, wy, redraw, despawn);
+                wx = uniform(wx); wy = uniform(wy);
+                redraw = __builtin_amdgcn_readfirstlane((int)redraw) != 0;
+                despawn = __builtin_amdgcn_readfirstlane((int)despawn) != 0;
+            } else if ((a.flags & 2u) && here) {
                 redraw = true;
                 nd = a.draws[i] + 1u;
-                const uint32_t pid = a.ids ? a.ids[i] : (uint32_t)i;     // the stream is keyed by the caller's index
                 wx = waypoint_coord(a.seed, pid, nd, 0u, a.world_side);
                 wy = waypoint_coord(a.seed, pid, nd, 1u, a.world_side);
             }
         }
         float nx = x, ny = y, nz = z;
         if (a.flags & 1u) { nx = fmaf(a.dt, nvx, x); ny = fmaf(a.dt, nvy, y); nz = fmaf(a.dt, nvz, z); }
+        if (despawn || gone) {                                           // destroy_pedestrian: parked as a ghost
+            const float2 pp = park_position(pid);
+            nx = pp.x; ny = pp.y; nvx = 0.f; nvy = 0.f; nvz = 0.f;
+        }
 
         if (lane == 0) {
             a.pk_next[i] = make_float4(nx, ny, nvx, nvy);
             if (Z3) a.zv_next[i] = make_float2(nz, nvz);
-            if (redraw) { a.own[i] = make_float4(wx, wy, o.z, o.w); a.draws[i] = nd; }
+            if (redraw) { a.own[i] = make_float4(wx, wy, o.z, o.w); if (!a.fsm.mode) a.draws[i] = nd; }
             if (a.rec) {
                 float* rc = a.rec;
                 const size_t n = (size_t)N;
@@ -736,8 +871,10 @@ __global__ __launch_bounds__(WAVE) void sfm_tile_bounds_kernel(const float4* __r
     float x0 = inf, y0 = inf, x1 = -inf, y1 = -inf, v = 0.0f;
     if (i < N) {
         const float4 s = pk[i];
-        x0 = x1 = s.x; y0 = y1 = s.y;
-        v = sqrtf(fmaf(s.z, s.z, s.w * s.w)) * 1.000001f;      // rounded up: the bound must stay a bound
+        if (fabsf(s.x) < 1.0e14f) {                             // despawned pedestrians are parked far away: not in the box
+            x0 = x1 = s.x; y0 = y1 = s.y;
+            v = sqrtf(fmaf(s.z, s.z, s.w * s.w)) * 1.000001f;  // rounded up: the bound must stay a bound
+        }
     }
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
@@ -1008,11 +1145,18 @@ __global__ __launch_bounds__(EPI_BLOCK) void sfm_sym_epilogue_kernel(const TickA
     sp = (sp == 0.0f) ? 1.0f : sp;
     const float fac = fminf(1.0f, (ts * a.max_speed_factor) / sp);
     nvx *= fac; nvy *= fac;
-    if (a.flags & 2u) {
+    const uint32_t pid = a.ids ? a.ids[i] : (uint32_t)i;
+    bool despawn = false;
+    const bool gone = a.fsm.mode && a.fsm.mode[pid] == MODE_DESPAWNED;
+    {
         const float ax_ = wx - x, ay_ = wy - y;
-        if (fmaf(ax_, ax_, ay_ * ay_) < a.arrive_thr2) {
+        const bool here = fmaf(ax_, ax_, ay_ * ay_) < a.arrive_thr2;
+        if (a.fsm.mode) {
+            bool changed = false;
+            if (here && !gone) fsm_arrived(a, pid, wx, wy, changed, despawn);
+            if (changed) a.own[i] = make_float4(wx, wy, o.z, o.w);
+        } else if ((a.flags & 2u) && here) {
             const uint32_t nd = nd0 + 1u;
-            const uint32_t pid = a.ids ? a.ids[i] : (uint32_t)i;
             wx = waypoint_coord(a.seed, pid, nd, 0u, a.world_side);
             wy = waypoint_coord(a.seed, pid, nd, 1u, a.world_side);
             a.own[i] = make_float4(wx, wy, o.z, o.w);
@@ -1021,6 +1165,7 @@ __global__ __launch_bounds__(EPI_BLOCK) void sfm_sym_epilogue_kernel(const TickA
     }
     float nx = x, ny = y;
     if (a.flags & 1u) { nx = fmaf(a.dt, nvx, x); ny = fmaf(a.dt, nvy, y); }
+    if (despawn || gone) { const float2 pp = park_position(pid); nx = pp.x; ny = pp.y; nvx = 0.f; nvy = 0.f; }
     a.pk_next[i] = make_float4(nx, ny, nvx, nvy);
     if (a.rec) {
         float* rc = a.rec;
@@ -1096,6 +1241,13 @@ static hipError_t launch_team(int ipw, bool z3, bool rad, const TickArgs& a, hip
 
 hipError_t launch_tick(int ipw, int team, bool z3, bool rad, const TickArgs& a, hipStream_t st) {
     return team == 4 ? launch_team<4>(ipw, z3, rad, a, st) : launch_team<1>(ipw, z3, rad, a, st);
+}
+
+hipError_t launch_modes(const TickArgs& a, hipStream_t st) {
+    const int n_local = a.i_end - a.i_begin;
+    if (n_local <= 0) return hipSuccess;
+    hipLaunchKernelGGL(sfm_mode_kernel, dim3((n_local + 255) / 256), dim3(256), 0, st, a);
+    return hipGetLastError();
 }
 
 hipError_t launch_geometry(bool rad, const TickArgs& a, hipStream_t st) {

@@ -212,6 +212,33 @@ class SfmEngine:
         self._check(self._lib.sfm_set_waypoint_stream(self._h, int(seed) & 0xFFFFFFFF, float(world_side),
                                                       float(arrive_threshold)), "sfm_set_waypoint_stream")
 
+    def set_mode_fsm(self, mode_managers, waypoint_lists, despawn_on_arrival=True, sim_time0=0.0, first_vehicle_extent=None):
+        """Hand the per-pedestrian mode objects (PedModeManager: current_mode, target_speed, initial_target_speed,
+        crossing_speed, crossing_safety_margin, next_mode_time) and the remaining waypoints of each pedestrian --
+        ``waypoint_lists[i]`` = [(waypoint(2 or 3), crossing_road), ...] like waypoint_dict (run_simulation.py:120-126) --
+        to the device, so ``run`` executes modes, gap acceptance, arrivals and despawns without the host."""
+        n = len(mode_managers)
+        f = lambda attr: f32([float(getattr(m, attr)) for m in mode_managers])
+        mode = np.ascontiguousarray([int(m.current_mode) for m in mode_managers], dtype=np.uint8)
+        off = np.zeros(n + 1, dtype=np.int32)
+        for i, lst in enumerate(waypoint_lists):
+            off[i + 1] = off[i] + len(lst)
+        flat = [w for lst in waypoint_lists for w in lst]
+        wx = f32([float(w[0][0]) for w in flat]); wy = f32([float(w[0][1]) for w in flat])
+        wc = np.ascontiguousarray([1 if w[1] else 0 for w in flat], dtype=np.uint8)
+        ext = None if first_vehicle_extent is None else f32(np.asarray(first_vehicle_extent, dtype=np.float64)[:2])
+        arrs = [f("target_speed"), f("initial_target_speed"), f("crossing_speed"), f("crossing_safety_margin"), f("next_mode_time")]
+        self._check(self._lib.sfm_set_mode_fsm(self._h, n, u8ptr(mode), *(fptr(a) for a in arrs), iptr(off),
+                                               fptr(wx) if len(flat) else None, fptr(wy) if len(flat) else None,
+                                               u8ptr(wc) if len(flat) else None, int(bool(despawn_on_arrival)),
+                                               float(sim_time0), fptr(ext)), "sfm_set_mode_fsm")
+
+    def modes(self):
+        """(mode uint8[N] with 255 = despawned, mode target speed float32[N], queue cursor int32[N])."""
+        m, t, c = np.zeros(self.n, np.uint8), np.zeros(self.n, np.float32), np.zeros(self.n, np.int32)
+        self._check(self._lib.sfm_download_modes(self._h, u8ptr(m), fptr(t), iptr(c)), "sfm_download_modes")
+        return m, t, c
+
     # ---- stepping ---------------------------------------------------------------------------------
     @staticmethod
     def _flags(integrate, redraw, record):

@@ -129,6 +129,26 @@ int sfm_set_shard(SfmHandle* h, int i_begin, int i_end);
  * (run_simulation.py:39) pedestrian i draws waypoint number k from hash(seed, i, k) in [0, world_side)^2. */
 int sfm_set_waypoint_stream(SfmHandle* h, uint32_t seed, float world_side, float arrive_threshold);
 
+/* Device-side pedestrian modes + waypoint queues + gap acceptance for device-resident runs (SURVEY.md section 8f
+ * rows 1 and 3): what PedModeManager (ped_mode_manager.py:12-70), PedState.apply_current_mode /
+ * update_next_waypoint (pedestrian_state.py:83-95), the CHECKING_TRAFFIC branch of PedestrianSimulation.tick
+ * (pedestrian_simulation.py:63-73, check_traffic.py:7-61) and the arrival loop of SimulationRunner.tick
+ * (run_simulation.py:118-132) do per pedestrian on the host.  All arrays are length N in the caller's index:
+ * mode (PedMode values 0..4), target_speed (the mode objects' current target_speed), initial_speed,
+ * crossing_speed, safety_margin, next_mode_time; wp_offsets[N+1] + wp_x/wp_y/wp_crossing: the remaining
+ * waypoints of each pedestrian (waypoint_dict) with the crossing flag of the leg; despawn_on_arrival as in
+ * run_simulation.py:41,127; sim_time0 = simulation time of the next tick; first_vehicle_extent = {ex, ey} of
+ * vehicle 0 (check_traffic.py:35-36 uses it for every vehicle) or NULL.  While set, every tick starts with the
+ * mode pass (target speeds, IDLE timers, gap acceptance, border-force mask) and arrivals pop the queue instead of
+ * the hash stream; exhausted pedestrians are despawned (parked as ghosts, mode 255).  N = 0 switches it off.
+ * Call after sfm_upload_state. */
+int sfm_set_mode_fsm(SfmHandle* h, int N, const uint8_t* mode, const float* target_speed, const float* initial_speed,
+                     const float* crossing_speed, const float* safety_margin, const float* next_mode_time,
+                     const int32_t* wp_offsets, const float* wp_x, const float* wp_y, const uint8_t* wp_crossing,
+                     int despawn_on_arrival, float sim_time0, const float* first_vehicle_extent);
+/* Current mode (255 = despawned), mode target speed and queue cursor of every pedestrian; NULL skips. */
+int sfm_download_modes(SfmHandle* h, uint8_t* mode, float* target_speed, int32_t* cursor);
+
 /* ---- stepping -------------------------------------------------------------------------------------- */
 
 /* One fused tick: F = sum of the enabled forces (pedestrian_simulation.py:81), v' = cap(v + dt*F,

@@ -76,4 +76,4 @@ class Case:
 
 
 def list_cases():
-    return sorted(os.path.join(GOLDEN_DIR, f) for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and f != "csv_case.npz")
+    return sorted(os.path.join(GOLDEN_DIR, f) for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and f not in ("csv_case.npz", "fsm_trace.npz"))

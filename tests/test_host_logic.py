@@ -41,6 +41,21 @@ def test_mode_fsm_transitions():
     assert PedModeManager("q", 1.0, PedMode.IDLE, 1.5, 1.0).target_speed == 1.0
 
 
+def test_mode_fsm_replays_the_reference_trace():
+    """tests/golden/fsm_trace.npz: 400 scripted tick / set_mode calls replayed on the REFERENCE's PedModeManager
+    (tests/golden/make_golden_fsm.py); the mirror must land in the same (mode, target_speed, next_mode_time)."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fsm_trace.npz"))
+    objs = [PedModeManager(f"p{k}", float(a), PedMode(int(b)), float(c), float(d)) for k, (a, b, c, d) in enumerate(z["init"])]
+    for (k, op, arg), (mode, target, nxt) in zip(z["script"], z["trace"]):
+        o = objs[int(k)]
+        if op == 0:
+            o.tick(float(arg))
+        else:
+            o.set_mode(PedMode(int(arg)))
+        assert (int(o.current_mode), o.target_speed, o.next_mode_time) == (int(mode), target, nxt)
+
+
 def _ped(i, mode=PedMode.WALKING_SIDEWALK):
     mm = PedModeManager(f"ped_{i}", 1.0 + 0.1 * i, mode, 1.5, 1.5)
     return (f"ped_{i}", 100 + i, [i, 2.0 * i, 0.0], [0.1, 0.2, 0.0], [10.0, 10.0, 0.0], mm, 0.3, 1.0 + 0.1 * i)
