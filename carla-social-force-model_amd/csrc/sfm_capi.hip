@@ -21,6 +21,13 @@ hipError_t launch_sym_pair(const TickArgs& a, const SymArgs& sa, hipStream_t st)
 hipError_t launch_sym_epilogue(const TickArgs& a, const SymArgs& sa, hipStream_t st);
 hipError_t launch_geometry(bool rad, const TickArgs& a, hipStream_t st);
 hipError_t launch_modes(const TickArgs& a, hipStream_t st);
+struct ReorderBufs { uint32_t *key_in, *key_out, *row_in, *row_out; void* temp; size_t temp_bytes; };
+size_t reorder_temp_bytes(int N);
+hipError_t launch_resort(const float4* pk, int N, float x0, float y0, const ReorderBufs& b, hipStream_t st);
+hipError_t launch_gather(const uint32_t* src, int N, const float4* pk_in, float4* pk_out, const float2* zv_in, float2* zv_out,
+                         const float4* own_in, float4* own_out, const float* rad_in, float* rad_out, const uint8_t* cr_in,
+                         uint8_t* cr_out, const uint32_t* dr_in, uint32_t* dr_out, const uint32_t* id_in, uint32_t* id_out,
+                         hipStream_t st);
 hipError_t launch_tile_bounds(const float4* pk, int N, float4* box, float* vmax, hipStream_t st);
 int probe_dpp_direction(hipStream_t st);
 hipError_t launch_dynamic_boxes(float4* ctr, const int* off, const float2* local, const float2* rot, float2* pts, int M,
@@ -85,7 +92,18 @@ struct SfmHandle {
     std::vector<uint32_t> perm;
     uint32_t* ids = nullptr;
     bool reordered = false;
-    int reorder_mode = -1;                 // SFM_REORDER: 0 off, 1 on, -1 auto (N >= 8192)
+    int reorder_mode = -1;                 // SFM_REORDER: 0 off, 1 on, -1 auto (N >= 2048)
+    // periodic device re-sort (sfm_reorder.hip): alternate copies of the per-row arrays + sort scratch
+    float4* own2 = nullptr;
+    float* radius2 = nullptr;
+    uint8_t* crossing2 = nullptr;
+    uint32_t *draws2 = nullptr, *ids2 = nullptr, *sort_buf = nullptr;
+    void* sort_temp = nullptr;
+    size_t sort_temp_bytes = 0;
+    int sort_cap = 0;
+    float org_x = 0.f, org_y = 0.f;
+    int resort_every = 64, ticks_since_sort = 0;
+    bool perm_stale = false;
     float r_max = 0.f;
     bool used_sym = false;
 
@@ -204,6 +222,8 @@ int sfm_create(const SfmParams* params, int device_id, SfmHandle** out) {
     if (ov) h->cut_mode = atoi(ov);
     ov = getenv("SFM_REORDER");
     if (ov) h->reorder_mode = atoi(ov);
+    ov = getenv("SFM_RESORT_EVERY");
+    if (ov) h->resort_every = atoi(ov);
     h->dpp_dir = probe_dpp_direction(nullptr);
     *out = h;
     return SFM_OK;
@@ -235,6 +255,8 @@ int sfm_destroy(SfmHandle* h) {
     if (h->tile_flag) hipFree(h->tile_flag);
     for (void* q : {(void*)h->f_mode, (void*)h->f_target, (void*)h->f_initial, (void*)h->f_crossing, (void*)h->f_margin,
                     (void*)h->f_next, (void*)h->f_off, (void*)h->f_cursor, (void*)h->f_xy, (void*)h->f_cross})
+        if (q) hipFree(q);
+    for (void* q : {(void*)h->own2, (void*)h->radius2, (void*)h->crossing2, (void*)h->draws2, (void*)h->ids2, (void*)h->sort_buf, h->sort_temp})
         if (q) hipFree(q);
     if (h->ids) hipFree(h->ids);
     if (h->tile_box) hipFree(h->tile_box);
@@ -426,12 +448,15 @@ int sfm_upload_state(SfmHandle* h, int N, const float* x, const float* y, const 
     std::vector<float> rr((size_t)n_pad, 0.f);
     std::vector<uint8_t> cm((size_t)n_pad, 0);
     // spatial order: Morton code of the 1 m cell (ties by index, so the order is a pure function of the state)
-    h->reordered = (h->reorder_mode == 1 || (h->reorder_mode < 0 && N >= 8192));
+    h->reordered = (h->reorder_mode == 1 || (h->reorder_mode < 0 && N >= 2048));
     h->perm.resize((size_t)N);
     std::iota(h->perm.begin(), h->perm.end(), 0u);
     if (h->reordered) {
         float x0 = x[0], y0 = y[0];
         for (int i = 1; i < N; ++i) { x0 = std::fmin(x0, x[i]); y0 = std::fmin(y0, y[i]); }
+        x0 = std::floor(x0) - 1024.0f;             // room for the crowd to drift: the device re-sort keeps this origin
+        y0 = std::floor(y0) - 1024.0f;
+        h->org_x = x0; h->org_y = y0;
         auto spread = [](uint32_t v) {          // 16 bits -> every other bit
             v &= 0xffffu; v = (v | (v << 8)) & 0x00ff00ffu; v = (v | (v << 4)) & 0x0f0f0f0fu;
             v = (v | (v << 2)) & 0x33333333u; v = (v | (v << 1)) & 0x55555555u; return v;
@@ -461,7 +486,24 @@ int sfm_upload_state(SfmHandle* h, int N, const float* x, const float* y, const 
     HIP_TRY(h, hipMemcpy(h->radius, rr.data(), sizeof(float) * (size_t)n_pad, hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->crossing, cm.data(), (size_t)n_pad, hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemset(h->draws, 0, sizeof(uint32_t) * (size_t)n_pad));
-    if (h->reordered) HIP_TRY(h, hipMemcpy(h->ids, h->perm.data(), sizeof(uint32_t) * (size_t)N, hipMemcpyHostToDevice));
+    if (h->reordered) {
+        HIP_TRY(h, hipMemcpy(h->ids, h->perm.data(), sizeof(uint32_t) * (size_t)N, hipMemcpyHostToDevice));
+        if (n_pad > h->sort_cap) {
+            HIP_TRY(h, dev_realloc(h->own2, (size_t)n_pad)); HIP_TRY(h, dev_realloc(h->radius2, (size_t)n_pad));
+            HIP_TRY(h, dev_realloc(h->crossing2, (size_t)n_pad)); HIP_TRY(h, dev_realloc(h->draws2, (size_t)n_pad));
+            HIP_TRY(h, dev_realloc(h->ids2, (size_t)n_pad)); HIP_TRY(h, dev_realloc(h->sort_buf, (size_t)n_pad * 4));
+            h->sort_temp_bytes = reorder_temp_bytes(n_pad);
+            if (h->sort_temp) { hipFree(h->sort_temp); h->sort_temp = nullptr; }
+            HIP_TRY(h, hipMalloc(&h->sort_temp, h->sort_temp_bytes > 0 ? h->sort_temp_bytes : 16));
+            h->sort_cap = n_pad;
+        }
+        HIP_TRY(h, hipMemset(h->own2, 0, sizeof(float4) * (size_t)n_pad));
+        HIP_TRY(h, hipMemset(h->radius2, 0, sizeof(float) * (size_t)n_pad));
+        HIP_TRY(h, hipMemset(h->crossing2, 0, (size_t)n_pad));
+        HIP_TRY(h, hipMemset(h->draws2, 0, sizeof(uint32_t) * (size_t)n_pad));
+    }
+    h->ticks_since_sort = 0;
+    h->perm_stale = false;
     // slab of the symmetric path: n_t x (n_t*64) float2 (8.6 GB at N = 262 144), up to 16 GiB of the 288 GB
     h->n_t = (N + WAVE - 1) / WAVE;
     const size_t need = (size_t)h->n_t * (size_t)h->n_t * WAVE;
@@ -621,6 +663,33 @@ static void fill_args(SfmHandle* h, TickArgs& a, uint32_t flags) {
     a.dynamics = Geo{h->dynamics.off, h->dynamics.pts, h->dynamics.ctr, nullptr, h->dynamics.K};
 }
 
+// Re-sorts the rows by the Morton code of their current cell (sfm_reorder.hip).  Whole-crowd handles only: a
+// shard's per-row data (waypoints, draw counters) of rows it does not own is not kept current.
+static int resort_rows(SfmHandle* h) {
+    const int N = h->N, np_ = h->N_pad;
+    ReorderBufs b{h->sort_buf, h->sort_buf + np_, h->sort_buf + 2 * (size_t)np_, h->sort_buf + 3 * (size_t)np_, h->sort_temp,
+                  h->sort_temp_bytes};
+    HIP_TRY(h, launch_resort(h->pk[h->cur], N, h->org_x, h->org_y, b, h->stream));
+    HIP_TRY(h, launch_gather(b.row_out, N, h->pk[h->cur], h->pk[h->cur ^ 1], h->z3 ? h->zv[h->cur] : nullptr, h->zv[h->cur ^ 1],
+                             h->own, h->own2, h->radius, h->radius2, h->crossing, h->crossing2, h->draws, h->draws2, h->ids,
+                             h->ids2, h->stream));
+    h->cur ^= 1;
+    std::swap(h->own, h->own2); std::swap(h->radius, h->radius2); std::swap(h->crossing, h->crossing2);
+    std::swap(h->draws, h->draws2); std::swap(h->ids, h->ids2);
+    h->perm_stale = true;
+    h->ticks_since_sort = 0;
+    return SFM_OK;
+}
+
+// downloads translate rows to the caller's index: fetch the row -> id map if a device re-sort changed it
+static int sync_perm(SfmHandle* h) {
+    if (!h->perm_stale) return SFM_OK;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpy(h->perm.data(), h->ids, sizeof(uint32_t) * (size_t)h->N, hipMemcpyDeviceToHost));
+    h->perm_stale = false;
+    return SFM_OK;
+}
+
 static int run_ticks(SfmHandle* h, int ticks, uint32_t flags) {
     int rc = bind(h);
     if (rc) return rc;
@@ -644,6 +713,13 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags) {
     HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
     int launches = 0;
     for (int t = 0; t < ticks; ++t) {
+        if (h->reordered && h->resort_every > 0 && (flags & SFM_TICK_INTEGRATE) && h->i_begin == 0 && h->i_end == h->N &&
+            h->ticks_since_sort >= h->resort_every) {
+            rc = resort_rows(h);
+            if (rc) return rc;
+            launches += 3;
+        }
+        ++h->ticks_since_sort;
         TickArgs a;
         fill_args(h, a, flags);
         // border / obstacle forces only need the tick's input state.  With the symmetric path they run on the
@@ -742,13 +818,19 @@ int sfm_run_recorded(SfmHandle* h, int ticks, uint32_t flags, int stride, float*
     if (!h->pk[0]) return fail(h, SFM_ERR_STATE, "sfm_upload_state has not been called");
     const int want = std::min(max_frames, (ticks + stride - 1) / stride);
     const size_t frame_recs = (size_t)h->N;
-    float4* stage = nullptr;                                   // pinned, rows in the library's order
+    float4* stage = nullptr;                                   // pinned, rows in the library's order ...
+    uint32_t* stage_ids = nullptr;                             // ... which a device re-sort may change between frames
     if (want > 0) HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&stage), sizeof(float4) * frame_recs * (size_t)want, 0));
+    if (want > 0 && h->reordered)
+        HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&stage_ids), sizeof(uint32_t) * frame_recs * (size_t)want, 0));
     int done = 0, f = 0;
     while (done < ticks && rc == SFM_OK) {
         if (f < want) {
             hipError_t e = hipMemcpyAsync(stage + frame_recs * (size_t)f, h->pk[h->cur], sizeof(float4) * frame_recs,
                                           hipMemcpyDeviceToHost, h->stream);
+            if (e == hipSuccess && stage_ids)
+                e = hipMemcpyAsync(stage_ids + frame_recs * (size_t)f, h->ids, sizeof(uint32_t) * frame_recs, hipMemcpyDeviceToHost,
+                                   h->stream);
             if (e != hipSuccess) { h->err = std::string("hipMemcpyAsync: ") + hipGetErrorString(e); rc = SFM_ERR_HIP; break; }
             ++f;
         }
@@ -761,12 +843,14 @@ int sfm_run_recorded(SfmHandle* h, int ticks, uint32_t flags, int stride, float*
         for (int k = 0; k < f; ++k)
             for (int s_ = 0; s_ < h->N; ++s_) {
                 const float4 v = stage[frame_recs * (size_t)k + s_];
-                float* dst = frames + ((size_t)k * h->N + h->perm[s_]) * 4;
+                const uint32_t id = stage_ids ? stage_ids[frame_recs * (size_t)k + s_] : h->perm[s_];
+                float* dst = frames + ((size_t)k * h->N + id) * 4;
                 dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
             }
         *n_frames = f;
     }
     if (stage) hipHostFree(stage);
+    if (stage_ids) hipHostFree(stage_ids);
     h->timing_valid = false;
     return rc;
 }
@@ -790,6 +874,8 @@ static int fetch_packed(SfmHandle* h, std::vector<float4>& pk, std::vector<float
 int sfm_download_velocities(SfmHandle* h, float* vx, float* vy, float* vz) {
     int rc = bind(h);
     if (rc) return rc;
+    rc = sync_perm(h);
+    if (rc) return rc;
     if (h->N == 0) return SFM_OK;
     if (!vx || !vy) return fail(h, SFM_ERR_INVALID, "vx / vy is NULL");
     std::vector<float4> pk;
@@ -808,6 +894,8 @@ int sfm_download_velocities(SfmHandle* h, float* vx, float* vy, float* vz) {
 int sfm_download_state(SfmHandle* h, float* x, float* y, float* z, float* vx, float* vy, float* vz, float* wx,
                        float* wy) {
     int rc = bind(h);
+    if (rc) return rc;
+    rc = sync_perm(h);
     if (rc) return rc;
     if (h->N == 0) return SFM_OK;
     std::vector<float4> pk, own;
@@ -837,6 +925,8 @@ int sfm_download_state(SfmHandle* h, float* x, float* y, float* z, float* vx, fl
 int sfm_download_forces(SfmHandle* h, int which, float* fx, float* fy, float* fz) {
     int rc = bind(h);
     if (rc) return rc;
+    rc = sync_perm(h);
+    if (rc) return rc;
     if (which < 0 || which > SFM_FORCE_TOTAL) return fail(h, SFM_ERR_INVALID, "unknown force index");
     if (h->N == 0) return SFM_OK;
     if (!h->rec_valid) return fail(h, SFM_ERR_STATE, "last tick did not run with SFM_TICK_RECORD_FORCES");
@@ -858,6 +948,8 @@ int sfm_download_forces(SfmHandle* h, int which, float* fx, float* fy, float* fz
 int sfm_get_arrived(SfmHandle* h, float threshold, uint8_t* mask) {
     int rc = bind(h);
     if (rc) return rc;
+    rc = sync_perm(h);
+    if (rc) return rc;
     if (h->N == 0) return SFM_OK;
     if (!mask) return fail(h, SFM_ERR_INVALID, "mask is NULL");
     const float thr2 = (float)((double)threshold * (double)threshold);
@@ -871,6 +963,8 @@ int sfm_get_arrived(SfmHandle* h, float threshold, uint8_t* mask) {
 
 int sfm_download_draw_counts(SfmHandle* h, uint32_t* counts) {
     int rc = bind(h);
+    if (rc) return rc;
+    rc = sync_perm(h);
     if (rc) return rc;
     if (h->N == 0) return SFM_OK;
     if (!counts) return fail(h, SFM_ERR_INVALID, "counts is NULL");

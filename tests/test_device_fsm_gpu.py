@@ -23,7 +23,8 @@ def _park(pid):
 
 
 @pytest.mark.parametrize("n", [160, 9000])
-def test_modes_queues_gap_acceptance_and_despawn(n):
+def test_modes_queues_gap_acceptance_and_despawn(n, monkeypatch):
+    monkeypatch.setenv("SFM_RESORT_EVERY", "3")            # rows are re-sorted on the device during the run (n = 9000)
     rng = np.random.default_rng(n)
     sc = scenarios.make_scenario(n, 4000 + n, n_borders=6, n_dynamic=6, border_len=(5.0, 20.0))
     cfg = default_sfm_config()

@@ -365,6 +365,7 @@ def test_spatial_reordering_is_invisible_to_the_caller(monkeypatch):
     for mode in ("0", "1"):
         monkeypatch.setenv("SFM_REORDER", mode)
         monkeypatch.setenv("SFM_CUTOFF", mode)
+        monkeypatch.setenv("SFM_RESORT_EVERY", "7")        # several device re-sorts inside the 40-tick run
         eng = SfmEngine(cfg, 0.05)
         try:
             eng.set_borders(sc.borders, sc.border_centers, sc.border_lengths)
@@ -389,9 +390,10 @@ def test_spatial_reordering_is_invisible_to_the_caller(monkeypatch):
 
 
 @pytest.mark.parametrize("n", [500, 9000])
-def test_recorded_run_matches_stepwise_downloads(n):
+def test_recorded_run_matches_stepwise_downloads(n, monkeypatch):
     """sfm_run_recorded: frame f is the state before tick f*stride, in the caller's index order (also when the
     rows are Morton-sorted internally, n = 9000), and recording does not perturb the run."""
+    monkeypatch.setenv("SFM_RESORT_EVERY", "3")            # the row order changes between the recorded frames
     sc = scenarios.make_scenario(n, 12, n_borders=4, border_len=(5.0, 20.0))
     cfg = default_sfm_config(("acceleration_force", "pedestrian_force", "border_force"))
     engs = []
