@@ -81,13 +81,16 @@ struct SfmHandle {
     int dpp_dir = 0;
     int sym_mode = -1;                     // SFM_SYM: 0 off, 1 on when eligible, -1 auto
     // tile-granular cutoff of provably negligible pedestrian pairs
-    float4* tile_box = nullptr;
+    float4* tile_box = nullptr;            // [2][n_t]: the lite cutoff ping-pongs (epilogue k writes the boxes of tick k+1)
     float* tile_vmax = nullptr;
+    int box_cur = 0;
+    bool boxes_valid = false;
     uint32_t* work = nullptr;
     int* work_count = nullptr;
     size_t work_cap = 0;
-    int cut_mode = -1;                     // SFM_CUTOFF: 0 off, 1 on, -1 auto (N >= 8192)
-    // spatial reordering: row s holds the caller's pedestrian perm[s] (Morton order of 1 m cells), so the 64-tiles
+    int cut_mode = -1;                     // SFM_CUTOFF: 0 off, 1 list-based, 2 lite, -1 auto (list-based for N >= 8192)
+    unsigned long long* stamps = nullptr;  // SFM_STAMPS diagnostic: per-workgroup timestamps of the symmetric pair kernel
+    // spatial reordering: row s holds the caller's pedestrian perm[s] (Hilbert-curve order of 1 m cells), so the 64-tiles
     // are compact squares; every download translates back.  Identity when off.
     std::vector<uint32_t> perm;
     uint32_t* ids = nullptr;
@@ -224,6 +227,13 @@ int sfm_create(const SfmParams* params, int device_id, SfmHandle** out) {
     if (ov) h->reorder_mode = atoi(ov);
     ov = getenv("SFM_RESORT_EVERY");
     if (ov) h->resort_every = atoi(ov);
+    if (getenv("SFM_STAMPS")) {
+        if (hipMalloc(reinterpret_cast<void**>(&h->stamps), sizeof(unsigned long long) * 3 * 8192) != hipSuccess) h->stamps = nullptr;
+        else {
+            FILE* f = fopen(getenv("SFM_STAMPS"), "w");   // the address is read back by the diagnostic script through the dump below
+            if (f) fclose(f);
+        }
+    }
     h->dpp_dir = probe_dpp_direction(nullptr);
     *out = h;
     return SFM_OK;
@@ -241,6 +251,14 @@ int sfm_destroy(SfmHandle* h) {
     if (!h) return SFM_OK;
     hipSetDevice(h->device);
     hipStreamSynchronize(h->stream);
+    if (h->stamps && getenv("SFM_STAMPS")) {       // diagnostic: dump the last launch's per-workgroup stamps
+        std::vector<unsigned long long> st(3 * 8192);
+        if (hipMemcpy(st.data(), h->stamps, sizeof(unsigned long long) * st.size(), hipMemcpyDeviceToHost) == hipSuccess) {
+            FILE* f = fopen(getenv("SFM_STAMPS"), "w");
+            if (f) { for (size_t b = 0; b < 8192; ++b) fprintf(f, "%llu %llu %llu\n", st[3 * b], st[3 * b + 1], st[3 * b + 2]); fclose(f); }
+        }
+        hipFree(h->stamps);
+    }
     for (int b = 0; b < 2; ++b) { if (h->pk[b]) hipFree(h->pk[b]); if (h->zv[b]) hipFree(h->zv[b]); }
     if (h->own) hipFree(h->own);
     if (h->radius) hipFree(h->radius);
@@ -447,7 +465,7 @@ int sfm_upload_state(SfmHandle* h, int N, const float* x, const float* y, const 
     std::vector<float2> zv((size_t)n_pad, make_float2(0.f, 0.f));
     std::vector<float> rr((size_t)n_pad, 0.f);
     std::vector<uint8_t> cm((size_t)n_pad, 0);
-    // spatial order: Morton code of the 1 m cell (ties by index, so the order is a pure function of the state)
+    // spatial order: Hilbert-curve index of the 1 m cell (ties by index, so the order is a pure function of the state)
     h->reordered = (h->reorder_mode == 1 || (h->reorder_mode < 0 && N >= 2048));
     h->perm.resize((size_t)N);
     std::iota(h->perm.begin(), h->perm.end(), 0u);
@@ -457,16 +475,24 @@ int sfm_upload_state(SfmHandle* h, int N, const float* x, const float* y, const 
         x0 = std::floor(x0) - 1024.0f;             // room for the crowd to drift: the device re-sort keeps this origin
         y0 = std::floor(y0) - 1024.0f;
         h->org_x = x0; h->org_y = y0;
-        auto spread = [](uint32_t v) {          // 16 bits -> every other bit
-            v &= 0xffffu; v = (v | (v << 8)) & 0x00ff00ffu; v = (v | (v << 4)) & 0x0f0f0f0fu;
-            v = (v | (v << 2)) & 0x33333333u; v = (v | (v << 1)) & 0x55555555u; return v;
+        auto hilbert = [](uint32_t cx_, uint32_t cy_) {      // same routine as hilbert_key() in sfm_reorder.hip
+            uint32_t d = 0;
+            for (uint32_t s_ = 32768u; s_ > 0; s_ >>= 1) {
+                const uint32_t rx = (cx_ & s_) ? 1u : 0u, ry = (cy_ & s_) ? 1u : 0u;
+                d += s_ * s_ * ((3u * rx) ^ ry);
+                if (ry == 0) {
+                    if (rx == 1) { cx_ = 65535u - cx_; cy_ = 65535u - cy_; }
+                    const uint32_t t_ = cx_; cx_ = cy_; cy_ = t_;
+                }
+            }
+            return d;
         };
         std::vector<uint32_t> key((size_t)N);
         for (int i = 0; i < N; ++i) {
             const float fx = x[i] - x0, fy = y[i] - y0;      // NaN / huge coordinates clamp to the last cell
             const uint32_t cxq = (fx >= 0.f && fx < 65535.f) ? (uint32_t)fx : 65535u;
             const uint32_t cyq = (fy >= 0.f && fy < 65535.f) ? (uint32_t)fy : 65535u;
-            key[i] = spread(cxq) | (spread(cyq) << 1);
+            key[i] = hilbert(cxq, cyq);
         }
         std::stable_sort(h->perm.begin(), h->perm.end(), [&](uint32_t a_, uint32_t b_) { return key[a_] < key[b_]; });
     }
@@ -515,8 +541,10 @@ int sfm_upload_state(SfmHandle* h, int N, const float* x, const float* y, const 
     // cutoff bookkeeping: per-tile box / max speed, and the work list of the symmetric kernel
     h->r_max = 0.f;
     if (rad) for (int i = 0; i < N; ++i) h->r_max = std::fmax(h->r_max, radius[i]);
-    HIP_TRY(h, dev_realloc(h->tile_box, (size_t)h->n_t));
-    HIP_TRY(h, dev_realloc(h->tile_vmax, (size_t)h->n_t));
+    HIP_TRY(h, dev_realloc(h->tile_box, (size_t)h->n_t * 2));
+    HIP_TRY(h, dev_realloc(h->tile_vmax, (size_t)h->n_t * 2));
+    h->box_cur = 0;
+    h->boxes_valid = false;
     {
         const size_t items = (size_t)h->n_t * (size_t)(h->n_t / 2 + 1);
         if (h->n_t < 65536 && items > h->work_cap) { HIP_TRY(h, dev_realloc(h->work, items)); h->work_cap = items; }
@@ -633,8 +661,15 @@ static void fill_args(SfmHandle* h, TickArgs& a, uint32_t flags) {
     a.geo = any_geo ? h->geo : nullptr;
     const bool cut = p.enabled[SFM_FORCE_PEDESTRIAN] && h->tile_box && h->N <= 64 * 64 * WAVE &&
                      (h->cut_mode == 1 || (h->cut_mode < 0 && h->N >= 8192)) && p.pedestrian.gamma > 0.f && p.pedestrian.lambda >= 0.f;
-    a.tile_box = cut ? h->tile_box : nullptr;
-    a.tile_vmax = cut ? h->tile_vmax : nullptr;
+    // "lite" cutoff (no work list): the pair kernel's workgroups test their own tile pair and the symmetric epilogue
+    // keeps the boxes current; needs the whole crowd on this handle and the symmetric path
+    const bool lite_ok = p.enabled[SFM_FORCE_PEDESTRIAN] && h->tile_box && !h->z3 && !h->rad && h->slab && h->i_begin == 0 &&
+                         h->i_end == h->N && h->sym_mode != 0 && p.pedestrian.gamma > 0.f && p.pedestrian.lambda >= 0.f;
+    const bool lite = lite_ok && !cut && h->cut_mode == 2;   // opt-in (SFM_CUTOFF=2): at N ~ 4096 it measured no net gain
+    a.tile_box = (cut || lite) ? h->tile_box + (size_t)h->box_cur * h->n_t : nullptr;
+    a.tile_vmax = (cut || lite) ? h->tile_vmax + (size_t)h->box_cur * h->n_t : nullptr;
+    a.tile_box_out = lite ? h->tile_box + (size_t)(h->box_cur ^ 1) * h->n_t : nullptr;
+    a.tile_vmax_out = lite ? h->tile_vmax + (size_t)(h->box_cur ^ 1) * h->n_t : nullptr;
     a.cut_scale = (float)((double)p.pedestrian.gamma * 41.0 * 0.6931471805599453 * 1.001);
     a.cut_pad = h->rad ? 2.0f * h->r_max * 1.001f : 0.f;
     if (h->fsm_on)
@@ -663,7 +698,7 @@ static void fill_args(SfmHandle* h, TickArgs& a, uint32_t flags) {
     a.dynamics = Geo{h->dynamics.off, h->dynamics.pts, h->dynamics.ctr, nullptr, h->dynamics.K};
 }
 
-// Re-sorts the rows by the Morton code of their current cell (sfm_reorder.hip).  Whole-crowd handles only: a
+// Re-sorts the rows by the Hilbert-curve index of their current cell (sfm_reorder.hip).  Whole-crowd handles only: a
 // shard's per-row data (waypoints, draw counters) of rows it does not own is not kept current.
 static int resort_rows(SfmHandle* h) {
     const int N = h->N, np_ = h->N_pad;
@@ -678,6 +713,7 @@ static int resort_rows(SfmHandle* h) {
     std::swap(h->draws, h->draws2); std::swap(h->ids, h->ids2);
     h->perm_stale = true;
     h->ticks_since_sort = 0;
+    h->boxes_valid = false;
     return SFM_OK;
 }
 
@@ -729,8 +765,9 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags) {
             HIP_TRY(h, launch_modes(a, h->stream));
             ++launches;
         }
-        if (a.tile_box) {                         // boxes / speeds of this tick's input state (all tiles)
-            HIP_TRY(h, launch_tile_bounds(a.pk_cur, h->N, h->tile_box, h->tile_vmax, h->stream));
+        const bool lite = a.tile_box_out != nullptr;
+        if (a.tile_box && !(lite && h->boxes_valid)) {   // boxes / speeds of this tick's input state (all tiles)
+            HIP_TRY(h, launch_tile_bounds(a.pk_cur, h->N, const_cast<float4*>(a.tile_box), const_cast<float*>(a.tile_vmax), h->stream));
             ++launches;
         }
         const bool fork = a.geo && n_local > 0 && sym && h->overlap_geo;
@@ -746,7 +783,8 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags) {
         }
         if (sym) {
             SymArgs sa{h->slab, h->tile_flag, h->n_t, h->n_t * WAVE, h->dpp_dir, getenv("SFM_DEBUG_STEPS") ? atoi(getenv("SFM_DEBUG_STEPS")) : -1,
-                       a.tile_box ? h->work : nullptr, a.tile_box ? h->work_count : nullptr};
+                       (a.tile_box && !lite) ? h->work : nullptr, (a.tile_box && !lite) ? h->work_count : nullptr,
+                       lite ? a.tile_box : nullptr, lite ? a.tile_vmax : nullptr, a.cut_scale, a.cut_pad, h->stamps};
             if (sa.work) launches += 1;
             HIP_TRY(h, launch_sym_pair(a, sa, h->stream));
             if (fork) HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
@@ -757,6 +795,9 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags) {
             ++launches;
         }
         h->cur ^= 1;
+        // lite cutoff: the epilogue left the next tick's boxes in the other buffer (valid only if this tick moved the crowd)
+        if (lite && sym) { h->box_cur ^= 1; h->boxes_valid = (flags & SFM_TICK_INTEGRATE) != 0; }
+        else h->boxes_valid = false;
         if (h->fsm_on) h->sim_time += h->prm.step_length;
         // CARLA-free runs: the vehicles move between ticks (run_simulation.py:77-95)
         if (h->dyn_boxes && (flags & SFM_TICK_INTEGRATE) && h->dynamics.K > 0) {
@@ -787,9 +828,11 @@ int sfm_profile_dominant_kernel(SfmHandle* h, int reps, float* avg_us) {
     TickArgs a;
     fill_args(h, a, 0);
     if (h->used_sym) a.geo = nullptr;
-    SymArgs sa{h->slab, h->tile_flag, h->n_t, h->n_t * WAVE, h->dpp_dir, -1, a.tile_box ? h->work : nullptr,
-               a.tile_box ? h->work_count : nullptr};
-    if (a.tile_box) HIP_TRY(h, launch_tile_bounds(a.pk_cur, h->N, h->tile_box, h->tile_vmax, h->stream));
+    const bool lite = a.tile_box_out != nullptr;
+    SymArgs sa{h->slab, h->tile_flag, h->n_t, h->n_t * WAVE, h->dpp_dir, -1, (a.tile_box && !lite) ? h->work : nullptr,
+               (a.tile_box && !lite) ? h->work_count : nullptr, lite ? a.tile_box : nullptr, lite ? a.tile_vmax : nullptr,
+               a.cut_scale, a.cut_pad, nullptr};
+    if (a.tile_box) HIP_TRY(h, launch_tile_bounds(a.pk_cur, h->N, const_cast<float4*>(a.tile_box), const_cast<float*>(a.tile_vmax), h->stream));
     HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
     for (int r = 0; r < reps; ++r) {
         if (h->used_sym) HIP_TRY(h, launch_sym_pair(a, sa, h->stream));

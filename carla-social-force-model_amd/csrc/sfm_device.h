@@ -85,6 +85,8 @@ struct TickArgs {
     const float* tile_vmax;   // [n_t] largest speed in the tile
     float cut_scale;          // gamma * 41 ln 2 (with margin): distance per unit of (lambda*(va+vb)+1)
     float cut_pad;            // 2 * largest radius when use_ped_radius, else 0
+    float4* tile_box_out;     // lite cutoff: the epilogue writes the boxes / speeds of the NEXT tick's state here
+    float* tile_vmax_out;
     FsmArgs fsm;
 };
 
@@ -98,6 +100,11 @@ struct SymArgs {
     int debug_steps;     // < 0: normal; >= 0: run only this many systolic steps per wave (timing probe, wrong results)
     const uint32_t* work;    // cutoff on: compacted list of (bx | shift << 16) tile-pair items, else null
     const int* work_count;
+    // "lite" cutoff for small crowds (no list): each workgroup tests its own tile pair and leaves if negligible
+    const float4* box;
+    const float* vmax;
+    float cut_scale, cut_pad;
+    unsigned long long* stamps;   // diagnostic builds of a run only (SFM_STAMPS): per workgroup {start, end} of s_memrealtime + HW id
 };
 
 }  // namespace sfm

@@ -939,6 +939,8 @@ __global__ __launch_bounds__(BLOCK) void sfm_pair_sym_kernel(const float4* __res
     const int wave = uniform(tid >> 6);
     const int n_t = sa.n_t;
     const int half_up = (n_t + 1) >> 1;
+    unsigned long long t_start = 0;
+    if (sa.stamps) t_start = __builtin_amdgcn_s_memrealtime();
     // work items: the (bx, shift) of the 2-D grid, or -- cutoff on -- entries of the compacted list, strided
     const int n_items = sa.work ? *sa.work_count : 1;
   for (int item = sa.work ? (int)blockIdx.x : 0; item < n_items; item += (sa.work ? (int)gridDim.x : 1)) {
@@ -971,6 +973,16 @@ __global__ __launch_bounds__(BLOCK) void sfm_pair_sym_kernel(const float4* __res
         const float4 pj = pk[tb * WAVE + lane];
         const int i_loc0 = (lane + sa.dir * sig0) & (WAVE - 1);
         const float4 pi0 = pk[ta * WAVE + i_loc0];
+        // lite cutoff (tested while the two loads above are in flight): every term of this tile pair is provably
+        // < 2^-40 A -> nothing to do; the epilogue applies the same test and does not read this pair's slab rows
+        if (sa.box && !sa.work && shift != 0 &&
+            tiles_negligible(sa.box[ta], sa.vmax[ta], sa.box[tb], sa.vmax[tb], c.lam, sa.cut_scale, sa.cut_pad)) {
+            if (sa.stamps && threadIdx.x == 0) {
+                const size_t b = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+                sa.stamps[3 * b] = t_start; sa.stamps[3 * b + 1] = t_start; sa.stamps[3 * b + 2] = ~0ull;
+            }
+            return;
+        }
         float xi = pi0.x, yi = pi0.y, vxi = pi0.z, vyi = pi0.w;
         auto step = [&](bool both) {
             float cx = 0.f, cy = 0.f, cz = 0.f, rinv;
@@ -1022,6 +1034,16 @@ __global__ __launch_bounds__(BLOCK) void sfm_pair_sym_kernel(const float4* __res
     }
     if (sa.work) __syncthreads();                 // LDS is reused by the next item
   }
+    if (sa.stamps && threadIdx.x == 0) {
+        const size_t b = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        sa.stamps[3 * b] = t_start;
+        sa.stamps[3 * b + 1] = __builtin_amdgcn_s_memrealtime();
+        sa.stamps[3 * b + 2] = ((unsigned long long)xcc << 32) | hw;
+    }
 }
 
 // Epilogue of the symmetric path: one workgroup of 16 waves per tile of 64 pedestrians.  The waves split the
@@ -1050,24 +1072,29 @@ __global__ __launch_bounds__(EPI_BLOCK) void sfm_sym_epilogue_kernel(const TickA
     // 1. slab column sums
     float2 acc = make_float2(0.f, 0.f);
     if (a.en_ped && a.tile_box) {
-        // cutoff on: each wave owns a contiguous range of partner tiles; its lanes test 64 of them at a time
-        // and only the rows of evaluated tile pairs are read (ascending order, deterministic)
+        // cutoff on: wave w owns partner tiles w, w+16, ...; its lanes test 64 of them at a time and only the rows of
+        // evaluated tile pairs are read (ascending order, deterministic)
         const float2* col = sa.slab + i;
         const float4 bt = a.tile_box[t];
         const float vt = a.tile_vmax[t];
-        const int per = (((sa.n_t + EPI_WAVES - 1) / EPI_WAVES) + WAVE - 1) / WAVE * WAVE;
-        const int u_end = min(sa.n_t, (wave + 1) * per);
-        for (int ub = wave * per; ub < u_end; ub += WAVE) {
-            const int u = ub + lane;
+        for (int base = wave; base < sa.n_t; base += EPI_WAVES * WAVE) {
+            const int u = base + EPI_WAVES * lane;
             bool keep = false;
-            if (u < u_end) keep = !tiles_negligible(bt, vt, a.tile_box[u], a.tile_vmax[u], a.ped.lam, a.cut_scale, a.cut_pad);
+            if (u < sa.n_t) keep = !tiles_negligible(bt, vt, a.tile_box[u], a.tile_vmax[u], a.ped.lam, a.cut_scale, a.cut_pad);
             unsigned long long m = __ballot(keep);
-            while (m) {
-                const int b = __ffsll((long long)m) - 1;
-                m &= m - 1;
-                const float2 v = col[(size_t)(ub + b) * sa.stride];
-                acc.x += v.x;
-                acc.y += v.y;
+            while (m) {                                   // up to four independent row loads in flight
+                float2 v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    v[q] = make_float2(0.f, 0.f);
+                    if (m) {
+                        const int b = __ffsll((long long)m) - 1;
+                        m &= m - 1;
+                        v[q] = col[(size_t)(base + EPI_WAVES * b) * sa.stride];
+                    }
+                }
+                acc.x += (v[0].x + v[1].x) + (v[2].x + v[3].x);
+                acc.y += (v[0].y + v[1].y) + (v[2].y + v[3].y);
             }
         }
     } else if (a.en_ped) {                                   // wave w takes partner tiles w, w+16, ...
@@ -1114,7 +1141,7 @@ __global__ __launch_bounds__(EPI_BLOCK) void sfm_sym_epilogue_kernel(const TickA
     if (exact) __syncthreads();
     if (wave != 0) return;
     if (exact && lane == 0) sa.tile_flag[t] = 0;      // re-armed for the next tick
-    if (i >= N) return;
+    const bool live = i < N;                           // padding rows ride along (wave reductions below) but never store
 
     // 4. lane-parallel epilogue for the 64 pedestrians of the tile
     float2 g = s_sum[0][lane];
@@ -1145,17 +1172,17 @@ __global__ __launch_bounds__(EPI_BLOCK) void sfm_sym_epilogue_kernel(const TickA
     sp = (sp == 0.0f) ? 1.0f : sp;
     const float fac = fminf(1.0f, (ts * a.max_speed_factor) / sp);
     nvx *= fac; nvy *= fac;
-    const uint32_t pid = a.ids ? a.ids[i] : (uint32_t)i;
+    const uint32_t pid = live ? (a.ids ? a.ids[i] : (uint32_t)i) : 0u;
     bool despawn = false;
-    const bool gone = a.fsm.mode && a.fsm.mode[pid] == MODE_DESPAWNED;
+    const bool gone = live && a.fsm.mode && a.fsm.mode[pid] == MODE_DESPAWNED;
     {
         const float ax_ = wx - x, ay_ = wy - y;
         const bool here = fmaf(ax_, ax_, ay_ * ay_) < a.arrive_thr2;
         if (a.fsm.mode) {
             bool changed = false;
-            if (here && !gone) fsm_arrived(a, pid, wx, wy, changed, despawn);
+            if (here && !gone && live) fsm_arrived(a, pid, wx, wy, changed, despawn);
             if (changed) a.own[i] = make_float4(wx, wy, o.z, o.w);
-        } else if ((a.flags & 2u) && here) {
+        } else if ((a.flags & 2u) && here && live) {
             const uint32_t nd = nd0 + 1u;
             wx = waypoint_coord(a.seed, pid, nd, 0u, a.world_side);
             wy = waypoint_coord(a.seed, pid, nd, 1u, a.world_side);
@@ -1166,8 +1193,21 @@ __global__ __launch_bounds__(EPI_BLOCK) void sfm_sym_epilogue_kernel(const TickA
     float nx = x, ny = y;
     if (a.flags & 1u) { nx = fmaf(a.dt, nvx, x); ny = fmaf(a.dt, nvy, y); }
     if (despawn || gone) { const float2 pp = park_position(pid); nx = pp.x; ny = pp.y; nvx = 0.f; nvy = 0.f; }
-    a.pk_next[i] = make_float4(nx, ny, nvx, nvy);
-    if (a.rec) {
+    if (live) a.pk_next[i] = make_float4(nx, ny, nvx, nvy);
+    if (a.tile_box_out) {                             // lite cutoff: box and largest speed of the tile in the NEXT state
+        const float inf = __builtin_inff();
+        const bool in_box = live && fabsf(nx) < 1.0e14f;
+        float x0 = in_box ? nx : inf, y0 = in_box ? ny : inf, x1 = in_box ? nx : -inf, y1 = in_box ? ny : -inf;
+        float v = in_box ? sqrtf(fmaf(nvx, nvx, nvy * nvy)) * 1.000001f : 0.0f;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            x0 = fminf(x0, __shfl_xor(x0, m)); y0 = fminf(y0, __shfl_xor(y0, m));
+            x1 = fmaxf(x1, __shfl_xor(x1, m)); y1 = fmaxf(y1, __shfl_xor(y1, m));
+            v = fmaxf(v, __shfl_xor(v, m));
+        }
+        if (lane == 0) { a.tile_box_out[t] = make_float4(x0, y0, x1, y1); a.tile_vmax_out[t] = v; }
+    }
+    if (a.rec && live) {
         float* rc = a.rec;
         const size_t n = (size_t)N;
         rc[(0 * 3 + 0) * n + i] = fax; rc[(0 * 3 + 1) * n + i] = fay; rc[(0 * 3 + 2) * n + i] = 0.f;

@@ -1,8 +1,8 @@
 // sfm_reorder.hip -- periodic spatial re-sort of the pedestrian rows on the device.
 //
 // The cutoff of sfm_kernels.hip (tiles_negligible) only pays while 64-row tiles are spatially compact.
-// sfm_upload_state puts the rows in Morton order once; pedestrians then walk ~0.06 m per tick, so a
-// device-resident run re-sorts every few dozen ticks: keys (Morton code of the 1 m cell) -> stable radix sort of
+// sfm_upload_state puts the rows in Hilbert order once; pedestrians then walk ~0.06 m per tick, so a
+// device-resident run re-sorts every few dozen ticks: keys (Hilbert-curve index of the 1 m cell) -> stable radix sort of
 // (key, row) with rocPRIM -> gather of every per-row array.  A pure function of the state, so it is
 // deterministic; despawned pedestrians (parked far away) sort to the end.
 #include "sfm_device.h"
@@ -12,13 +12,23 @@
 
 namespace sfm {
 
-__device__ __forceinline__ uint32_t spread16(uint32_t v) {
-    v &= 0xffffu; v = (v | (v << 8)) & 0x00ff00ffu; v = (v | (v << 4)) & 0x0f0f0f0fu;
-    v = (v | (v << 2)) & 0x33333333u; v = (v | (v << 1)) & 0x55555555u;
-    return v;
+// Position along the Hilbert curve of the 65536 x 65536 grid of 1 m cells.  Unlike the Z-order curve it has no
+// jumps: any 64 consecutive pedestrians along it occupy one compact patch, so fixed 64-row tiles have small
+// bounding boxes wherever the tile boundaries fall.  (Same routine on the host in sfm_capi.hip.)
+__host__ __device__ inline uint32_t hilbert_key(uint32_t x, uint32_t y) {
+    uint32_t d = 0;
+    for (uint32_t s = 32768u; s > 0; s >>= 1) {
+        const uint32_t rx = (x & s) ? 1u : 0u, ry = (y & s) ? 1u : 0u;
+        d += s * s * ((3u * rx) ^ ry);
+        if (ry == 0) {
+            if (rx == 1) { x = 65535u - x; y = 65535u - y; }
+            const uint32_t t = x; x = y; y = t;
+        }
+    }
+    return d;
 }
 
-__global__ void sfm_morton_keys_kernel(const float4* __restrict__ pk, int N, float x0, float y0, uint32_t* __restrict__ key,
+__global__ void sfm_cell_keys_kernel(const float4* __restrict__ pk, int N, float x0, float y0, uint32_t* __restrict__ key,
                                        uint32_t* __restrict__ row) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= N) return;
@@ -26,7 +36,7 @@ __global__ void sfm_morton_keys_kernel(const float4* __restrict__ pk, int N, flo
     const float fx = p.x - x0, fy = p.y - y0;
     const uint32_t cx = (fx >= 0.f && fx < 65535.f) ? (uint32_t)fx : (fx < 0.f ? 0u : 65535u);
     const uint32_t cy = (fy >= 0.f && fy < 65535.f) ? (uint32_t)fy : (fy < 0.f ? 0u : 65535u);
-    key[s] = (fabsf(p.x) < 1.0e14f) ? (spread16(cx) | (spread16(cy) << 1)) : 0xffffffffu;   // parked ghosts last
+    key[s] = (fabsf(p.x) < 1.0e14f) ? hilbert_key(cx, cy) : 0xffffffffu;   // parked ghosts last
     row[s] = (uint32_t)s;
 }
 
@@ -64,7 +74,7 @@ size_t reorder_temp_bytes(int N) {
 
 // keys -> sort -> row_out[s] = old row that moves to row s
 hipError_t launch_resort(const float4* pk, int N, float x0, float y0, const ReorderBufs& b, hipStream_t st) {
-    hipLaunchKernelGGL(sfm_morton_keys_kernel, dim3((N + 255) / 256), dim3(256), 0, st, pk, N, x0, y0, b.key_in, b.row_in);
+    hipLaunchKernelGGL(sfm_cell_keys_kernel, dim3((N + 255) / 256), dim3(256), 0, st, pk, N, x0, y0, b.key_in, b.row_in);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     size_t bytes = b.temp_bytes;

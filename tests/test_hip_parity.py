@@ -362,8 +362,8 @@ def test_spatial_reordering_is_invisible_to_the_caller(monkeypatch):
     perm = np.random.default_rng(5).permutation(n)
     cfg = default_sfm_config(("acceleration_force", "pedestrian_force", "border_force", "static_obstacle_force"))
     out = {}
-    for mode in ("0", "1"):
-        monkeypatch.setenv("SFM_REORDER", mode)
+    for mode in ("0", "1", "2"):                        # off / list-based cutoff / "lite" cutoff (boxes kept by the epilogue)
+        monkeypatch.setenv("SFM_REORDER", "0" if mode == "0" else "1")
         monkeypatch.setenv("SFM_CUTOFF", mode)
         monkeypatch.setenv("SFM_RESORT_EVERY", "7")        # several device re-sorts inside the 40-tick run
         eng = SfmEngine(cfg, 0.05)
@@ -379,14 +379,15 @@ def test_spatial_reordering_is_invisible_to_the_caller(monkeypatch):
             out[mode] = (F, arrived, *eng.state(), eng.draw_counts())
         finally:
             eng.close()
-    a, b = out["0"], out["1"]
+    a = out["0"]
     scale = np.abs(a[0]).max()
-    assert np.max(np.abs(a[0] - b[0])) <= 2e-5 * scale                   # same forces, pedestrian by pedestrian
-    assert np.array_equal(a[1], b[1])
-    assert b[5].sum() > 0 and np.array_equal(a[5], b[5])                 # same pedestrians redrew
-    moved = a[5] > 0
-    assert np.allclose(a[4][moved], b[4][moved], atol=1e-4)              # ... to the same waypoints
-    assert np.median(np.linalg.norm(a[2] - b[2], axis=1)) < 1e-3         # trajectories agree (fp32 order effects only)
+    for b in (out["1"], out["2"]):
+        assert np.max(np.abs(a[0] - b[0])) <= 2e-5 * scale                   # same forces, pedestrian by pedestrian
+        assert np.array_equal(a[1], b[1])
+        assert b[5].sum() > 0 and np.array_equal(a[5], b[5])                 # same pedestrians redrew
+        moved = a[5] > 0
+        assert np.allclose(a[4][moved], b[4][moved], atol=1e-4)              # ... to the same waypoints
+        assert np.median(np.linalg.norm(a[2] - b[2], axis=1)) < 1e-3         # trajectories agree (fp32 order effects only)
 
 
 @pytest.mark.parametrize("n", [500, 9000])
