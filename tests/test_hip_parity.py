@@ -150,8 +150,11 @@ def test_symmetric_path_coincident_pairs(monkeypatch):
         eng.close()
 
 
+@pytest.mark.parametrize("reorder", ["0", "1"])
 @pytest.mark.parametrize("variant", ["radius", "z"])
-def test_radius_and_z_variants_vs_oracle(variant):
+def test_radius_and_z_variants_vs_oracle(variant, reorder, monkeypatch):
+    monkeypatch.setenv("SFM_REORDER", reorder)          # with and without the internal spatial row order
+    monkeypatch.setenv("SFM_CUTOFF", reorder)           # ... and the tile cutoff (radius pads the reach by 2 r_max)
     n = 700
     sc = scenarios.make_scenario(n, 77, n_borders=30, n_static=12, n_dynamic=6, z_spread=1.0 if variant == "z" else 0.0,
                                  border_len=(5.0, 20.0))
