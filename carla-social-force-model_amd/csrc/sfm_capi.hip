@@ -21,9 +21,9 @@ hipError_t launch_sym_pair(const TickArgs& a, const SymArgs& sa, hipStream_t st)
 hipError_t launch_sym_epilogue(const TickArgs& a, const SymArgs& sa, hipStream_t st);
 hipError_t launch_geometry(bool rad, const TickArgs& a, hipStream_t st);
 hipError_t launch_modes(const TickArgs& a, hipStream_t st);
-struct ReorderBufs { uint32_t *key_in, *key_out, *row_in, *row_out; void* temp; size_t temp_bytes; };
+struct ReorderBufs { unsigned long long *key64_in, *key64_out; uint32_t *row_a, *row_b, *key32_in, *key32_out; void* temp; size_t temp_bytes; };
 size_t reorder_temp_bytes(int N);
-hipError_t launch_resort(const float4* pk, int N, float x0, float y0, const ReorderBufs& b, hipStream_t st);
+hipError_t launch_resort(const float4* pk, int N, int strip_rows, const ReorderBufs& b, hipStream_t st);
 hipError_t launch_gather(const uint32_t* src, int N, const float4* pk_in, float4* pk_out, const float2* zv_in, float2* zv_out,
                          const float4* own_in, float4* own_out, const float* rad_in, float* rad_out, const uint8_t* cr_in,
                          uint8_t* cr_out, const uint32_t* dr_in, uint32_t* dr_out, const uint32_t* id_in, uint32_t* id_out,
@@ -90,7 +90,7 @@ struct SfmHandle {
     size_t work_cap = 0;
     int cut_mode = -1;                     // SFM_CUTOFF: 0 off, 1 list-based, 2 lite, -1 auto (list-based for N >= 8192)
     unsigned long long* stamps = nullptr;  // SFM_STAMPS diagnostic: per-workgroup timestamps of the symmetric pair kernel
-    // spatial reordering: row s holds the caller's pedestrian perm[s] (Hilbert-curve order of 1 m cells), so the 64-tiles
+    // spatial reordering: row s holds the caller's pedestrian perm[s] (strips in x, each sorted by y: sfm_reorder.hip), so the 64-tiles
     // are compact squares; every download translates back.  Identity when off.
     std::vector<uint32_t> perm;
     uint32_t* ids = nullptr;
@@ -104,7 +104,7 @@ struct SfmHandle {
     void* sort_temp = nullptr;
     size_t sort_temp_bytes = 0;
     int sort_cap = 0;
-    float org_x = 0.f, org_y = 0.f;
+    int strip_rows = WAVE;                      // rows per x-strip of the spatial packing (multiple of 64)
     int resort_every = 64, ticks_since_sort = 0;
     bool perm_stale = false;
     float r_max = 0.f;
@@ -465,36 +465,32 @@ int sfm_upload_state(SfmHandle* h, int N, const float* x, const float* y, const 
     std::vector<float2> zv((size_t)n_pad, make_float2(0.f, 0.f));
     std::vector<float> rr((size_t)n_pad, 0.f);
     std::vector<uint8_t> cm((size_t)n_pad, 0);
-    // spatial order: Hilbert-curve index of the 1 m cell (ties by index, so the order is a pure function of the state)
+    // spatial order (sfm_reorder.hip): sort by x, cut into strips of strip_rows rows, sort each strip by y, so every
+    // 64-row tile is the content of one axis-aligned rectangle.  Stable sorts on order-preserving integer keys: the
+    // order is a pure function of the uploaded state, identical on every rank.
     h->reordered = (h->reorder_mode == 1 || (h->reorder_mode < 0 && N >= 2048));
     h->perm.resize((size_t)N);
     std::iota(h->perm.begin(), h->perm.end(), 0u);
     if (h->reordered) {
-        float x0 = x[0], y0 = y[0];
-        for (int i = 1; i < N; ++i) { x0 = std::fmin(x0, x[i]); y0 = std::fmin(y0, y[i]); }
-        x0 = std::floor(x0) - 1024.0f;             // room for the crowd to drift: the device re-sort keeps this origin
-        y0 = std::floor(y0) - 1024.0f;
-        h->org_x = x0; h->org_y = y0;
-        auto hilbert = [](uint32_t cx_, uint32_t cy_) {      // same routine as hilbert_key() in sfm_reorder.hip
-            uint32_t d = 0;
-            for (uint32_t s_ = 32768u; s_ > 0; s_ >>= 1) {
-                const uint32_t rx = (cx_ & s_) ? 1u : 0u, ry = (cy_ & s_) ? 1u : 0u;
-                d += s_ * s_ * ((3u * rx) ^ ry);
-                if (ry == 0) {
-                    if (rx == 1) { cx_ = 65535u - cx_; cy_ = 65535u - cy_; }
-                    const uint32_t t_ = cx_; cx_ = cy_; cy_ = t_;
-                }
-            }
-            return d;
-        };
-        std::vector<uint32_t> key((size_t)N);
+        auto float_key = [](float v) { uint32_t b; memcpy(&b, &v, sizeof(b)); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); };
+        // strips: about sqrt(#tiles) of them, corrected for the aspect of the crowd's extent so that tiles come out square
+        float x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
         for (int i = 0; i < N; ++i) {
-            const float fx = x[i] - x0, fy = y[i] - y0;      // NaN / huge coordinates clamp to the last cell
-            const uint32_t cxq = (fx >= 0.f && fx < 65535.f) ? (uint32_t)fx : 65535u;
-            const uint32_t cyq = (fy >= 0.f && fy < 65535.f) ? (uint32_t)fy : 65535u;
-            key[i] = hilbert(cxq, cyq);
+            if (std::fabs(x[i]) < 1.0e12f && std::fabs(y[i]) < 1.0e12f) {
+                x0 = std::fmin(x0, x[i]); x1 = std::fmax(x1, x[i]); y0 = std::fmin(y0, y[i]); y1 = std::fmax(y1, y[i]);
+            }
         }
-        std::stable_sort(h->perm.begin(), h->perm.end(), [&](uint32_t a_, uint32_t b_) { return key[a_] < key[b_]; });
+        const int n_tiles = (N + WAVE - 1) / WAVE;
+        double aspect = (x1 > x0 && y1 > y0) ? (double)(x1 - x0) / (double)(y1 - y0) : 1.0;
+        aspect = std::fmin(std::fmax(aspect, 1.0 / 64.0), 64.0);
+        const int n_strips = std::max(1, std::min(n_tiles, (int)std::lround(std::sqrt((double)n_tiles * aspect))));
+        h->strip_rows = WAVE * ((n_tiles + n_strips - 1) / n_strips);
+        std::vector<uint32_t> kx((size_t)N), ky((size_t)N);
+        for (int i = 0; i < N; ++i) { kx[i] = float_key(x[i]); ky[i] = float_key(y[i]); }
+        std::stable_sort(h->perm.begin(), h->perm.end(), [&](uint32_t a_, uint32_t b_) { return kx[a_] < kx[b_]; });
+        for (int r0 = 0; r0 < N; r0 += h->strip_rows)
+            std::stable_sort(h->perm.begin() + r0, h->perm.begin() + std::min(N, r0 + h->strip_rows),
+                             [&](uint32_t a_, uint32_t b_) { return ky[a_] < ky[b_]; });
     }
     for (int s_ = 0; s_ < N; ++s_) {
         const int i = (int)h->perm[s_];
@@ -517,7 +513,7 @@ int sfm_upload_state(SfmHandle* h, int N, const float* x, const float* y, const 
         if (n_pad > h->sort_cap) {
             HIP_TRY(h, dev_realloc(h->own2, (size_t)n_pad)); HIP_TRY(h, dev_realloc(h->radius2, (size_t)n_pad));
             HIP_TRY(h, dev_realloc(h->crossing2, (size_t)n_pad)); HIP_TRY(h, dev_realloc(h->draws2, (size_t)n_pad));
-            HIP_TRY(h, dev_realloc(h->ids2, (size_t)n_pad)); HIP_TRY(h, dev_realloc(h->sort_buf, (size_t)n_pad * 4));
+            HIP_TRY(h, dev_realloc(h->ids2, (size_t)n_pad)); HIP_TRY(h, dev_realloc(h->sort_buf, (size_t)n_pad * 8));
             h->sort_temp_bytes = reorder_temp_bytes(n_pad);
             if (h->sort_temp) { hipFree(h->sort_temp); h->sort_temp = nullptr; }
             HIP_TRY(h, hipMalloc(&h->sort_temp, h->sort_temp_bytes > 0 ? h->sort_temp_bytes : 16));
@@ -698,14 +694,15 @@ static void fill_args(SfmHandle* h, TickArgs& a, uint32_t flags) {
     a.dynamics = Geo{h->dynamics.off, h->dynamics.pts, h->dynamics.ctr, nullptr, h->dynamics.K};
 }
 
-// Re-sorts the rows by the Hilbert-curve index of their current cell (sfm_reorder.hip).  Whole-crowd handles only: a
+// Re-packs the rows spatially (strips in x, sorted by y: sfm_reorder.hip).  Whole-crowd handles only: a
 // shard's per-row data (waypoints, draw counters) of rows it does not own is not kept current.
 static int resort_rows(SfmHandle* h) {
     const int N = h->N, np_ = h->N_pad;
-    ReorderBufs b{h->sort_buf, h->sort_buf + np_, h->sort_buf + 2 * (size_t)np_, h->sort_buf + 3 * (size_t)np_, h->sort_temp,
-                  h->sort_temp_bytes};
-    HIP_TRY(h, launch_resort(h->pk[h->cur], N, h->org_x, h->org_y, b, h->stream));
-    HIP_TRY(h, launch_gather(b.row_out, N, h->pk[h->cur], h->pk[h->cur ^ 1], h->z3 ? h->zv[h->cur] : nullptr, h->zv[h->cur ^ 1],
+    uint32_t* w = h->sort_buf;                     // 8 N_pad words: two 64-bit key arrays, two row arrays, two 32-bit key arrays
+    ReorderBufs b{reinterpret_cast<unsigned long long*>(w), reinterpret_cast<unsigned long long*>(w + 2 * (size_t)np_),
+                  w + 4 * (size_t)np_, w + 5 * (size_t)np_, w + 6 * (size_t)np_, w + 7 * (size_t)np_, h->sort_temp, h->sort_temp_bytes};
+    HIP_TRY(h, launch_resort(h->pk[h->cur], N, h->strip_rows, b, h->stream));
+    HIP_TRY(h, launch_gather(b.row_b, N, h->pk[h->cur], h->pk[h->cur ^ 1], h->z3 ? h->zv[h->cur] : nullptr, h->zv[h->cur ^ 1],
                              h->own, h->own2, h->radius, h->radius2, h->crossing, h->crossing2, h->draws, h->draws2, h->ids,
                              h->ids2, h->stream));
     h->cur ^= 1;
@@ -748,12 +745,18 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags) {
                   h->rad ? "true" : "false", team);
     HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
     int launches = 0;
+    bool order_pays;                                // compact tiles only matter to the tile cutoff and the geometry kernel
+    {
+        TickArgs probe;
+        fill_args(h, probe, flags);
+        order_pays = probe.geo != nullptr || probe.tile_box != nullptr;
+    }
     for (int t = 0; t < ticks; ++t) {
         if (h->reordered && h->resort_every > 0 && (flags & SFM_TICK_INTEGRATE) && h->i_begin == 0 && h->i_end == h->N &&
-            h->ticks_since_sort >= h->resort_every) {
+            h->ticks_since_sort >= h->resort_every && order_pays) {
             rc = resort_rows(h);
             if (rc) return rc;
-            launches += 3;
+            launches += 5;
         }
         ++h->ticks_since_sort;
         TickArgs a;

@@ -53,19 +53,19 @@ __device__ __forceinline__ float atan2_poly(float s, float c) {
 //   tan(theta/2) = s / (1 + c)  ->  theta = 2 atan(s / (1 + |c|)) for c >= 0, sign(s)*pi - that for c < 0.
 // The ratio is in [-1, 1] for every quadrant, so there is no octant swap, and theta = r * P(r^2) keeps
 // full RELATIVE precision for small angles (head-on encounters, where the force is largest).
-// 9-coefficient minimax fit of 2*atan(r)/r on [0,1], relative error 1.4e-8.  (0,0) -> 0.
+// 8-coefficient minimax fit of 2*atan(r)/r on [0,1], relative error 8.9e-8 (below the 2^-22 rad resolution of
+// the angle between two fp32-rounded directions).  (0,0) -> 0.
 __device__ __forceinline__ float atan2_unit(float s, float c) {
     const float r = s * rcp(1.0f + fabsf(c));
     const float z = r * r;
-    float p = 0.0058070349296077258f;
-    p = fmaf(p, z, -0.032565738120124484f);
-    p = fmaf(p, z, 0.086078288980656448f);
-    p = fmaf(p, z, -0.15067314789328404f);
-    p = fmaf(p, z, 0.21309337545480259f);
-    p = fmaf(p, z, -0.28414262998659057f);
-    p = fmaf(p, z, 0.39986107686183325f);
-    p = fmaf(p, z, -0.66666187889991357f);
-    p = fmaf(p, z, 1.9999999727316076f);
+    float p = -0.0095607885413262813f;
+    p = fmaf(p, z, 0.049113825228842972f);
+    p = fmaf(p, z, -0.11980885478692463f);
+    p = fmaf(p, z, 0.1988547939908939f);
+    p = fmaf(p, z, -0.28058826128196529f);
+    p = fmaf(p, z, 0.39942748114880167f);
+    p = fmaf(p, z, -0.66664186893326649f);
+    p = fmaf(p, z, 1.9999998228145017f);
     const float a = p * r;
     return (c < 0.0f) ? (copysignf(3.14159265358979324f, s) - a) : a;
 }
@@ -77,8 +77,8 @@ __device__ __forceinline__ float atan2_unit(float s, float c) {
 // np.arctan2(0,0) = 0, -0/0 = NaN); the fast form differs from it only for coincident pairs, which the
 // caller detects through `rinv_out` and recomputes.
 template <bool Z3, bool RAD, bool EXACT>
-__device__ __forceinline__ void moussaid(const IxConst& c, float dx, float dy, float dz, float dvx, float dvy,
-                                         float dvz, float rsum, float& gx, float& gy, float& gz,
+__device__ __forceinline__ void moussaid(const IxConst& c, float dx, float dy, float dz, float dvx,
+                                         float dvy, float dvz, float rsum, float& gx, float& gy, float& gz,
                                          float& rinv_out) {
     const float d2 = fmaf(dx, dx, fmaf(dy, dy, Z3 ? fmaf(dz, dz, TINY) : TINY));
     const float rinv = rsq(d2);
@@ -159,67 +159,63 @@ __device__ __forceinline__ bool tiles_negligible(const float4 ba, const float va
 }
 
 // ---- nearest sampled point of a polyline: np.argmin's first-minimum rule (forces.py:154,228) -------------
-// A wave serves FOUR polylines at once: each row of 16 lanes scans one polyline [o0,o1) (o0/o1 are per-lane,
-// equal within a row) and the (distance, index, point) minimum is all-reduced inside the row with four DPP
-// row rotations -- VALU moves, no LDS traffic, and four independent load chains in flight per wave.  An empty
-// polyline yields a far-away sentinel point whose force term underflows to exactly 0.
-template <int R>
-__device__ __forceinline__ float ror16(float v) {
-    const int b = __float_as_int(v);
-    return __int_as_float(__builtin_amdgcn_update_dpp(b, b, 0x120 + R /* row_ror:R */, 0xf, 0xf, false));
+// One LANE per pedestrian, the polyline [o0,o1) is wave-uniform.  A trip brings 64 points in with one coalesced
+// load (the next trip's load is in flight meanwhile), parks them in the wave's LDS row, and every lane walks them
+// through broadcast ds_read_b128 (two points each).  The running minimum is kept per GROUP of 8 points (4 ops
+// per distance + one min3 tree + one compare per group instead of a compare-select pair per point); at the end
+// of the trip a lane whose minimum moved re-reads its winning group from the row and takes the first slot
+// whose distance -- recomputed with the same operations, so bit-identical -- equals the minimum.
+// Groups in ascending order with a strict `<`, first equal slot inside the group: np.argmin's first-minimum rule.
+// Slots past the end hold copies of the last point (they can tie with it, never beat it, and come later).
+// LDS operations of one wave execute in order, so the row needs no barrier.
+// An empty polyline yields a far-away sentinel whose force term underflows to exactly 0.
+__device__ __forceinline__ float dist2(float x, float y, float px, float py) {
+    const float ax = x - px, ay = y - py;
+    return fmaf(ax, ax, ay * ay);
 }
-template <int R>
-__device__ __forceinline__ int ror16(int v) {
-    return __builtin_amdgcn_update_dpp(v, v, 0x120 + R, 0xf, 0xf, false);
-}
-template <int R>
-__device__ __forceinline__ void argmin_step(float& bd, int& bi, float& bx, float& by) {
-    const float od = ror16<R>(bd), ox = ror16<R>(bx), oy = ror16<R>(by);
-    const int oi = ror16<R>(bi);
-    const bool take = (od < bd) | ((od == bd) & (oi < bi));
-    bd = take ? od : bd;
-    bi = take ? oi : bi;
-    bx = take ? ox : bx;
-    by = take ? oy : by;
-}
-__device__ __forceinline__ float2 row_nearest(const float2* __restrict__ pts, int o0, int o1, float x, float y, int gl) {
-    float bd = __builtin_inff(), bx = 3.0e15f, by = 3.0e15f;
-    int bi = 0x7fffffff;
-    // four independent loads per trip (indices clamped into the polyline, results masked), compared in
-    // ascending index order so the first minimum wins
-    for (int p = o0 + gl; p < o1; p += 64) {
-        const int last = o1 - 1;
-        const float2 q0 = pts[p], q1 = pts[min(p + 16, last)], q2 = pts[min(p + 32, last)], q3 = pts[min(p + 48, last)];
-        const float d0 = fmaf(x - q0.x, x - q0.x, (y - q0.y) * (y - q0.y));
-        const float d1 = fmaf(x - q1.x, x - q1.x, (y - q1.y) * (y - q1.y));
-        const float d2 = fmaf(x - q2.x, x - q2.x, (y - q2.y) * (y - q2.y));
-        const float d3 = fmaf(x - q3.x, x - q3.x, (y - q3.y) * (y - q3.y));
-        if (d0 < bd) { bd = d0; bi = p; bx = q0.x; by = q0.y; }
-        if ((p + 16 < o1) & (d1 < bd)) { bd = d1; bi = p + 16; bx = q1.x; by = q1.y; }
-        if ((p + 32 < o1) & (d2 < bd)) { bd = d2; bi = p + 32; bx = q2.x; by = q2.y; }
-        if ((p + 48 < o1) & (d3 < bd)) { bd = d3; bi = p + 48; bx = q3.x; by = q3.y; }
-    }
-    argmin_step<8>(bd, bi, bx, by);
-    argmin_step<4>(bd, bi, bx, by);
-    argmin_step<2>(bd, bi, bx, by);
-    argmin_step<1>(bd, bi, bx, by);
-    return make_float2(bx, by);
-}
-
-// Pops up to four set bits of m (uniform) and returns the one belonging to this lane's row, or -1.
-__device__ __forceinline__ int pop4(unsigned long long& m, int row, int& n_popped) {
-    int mine = -1;
-    n_popped = 0;
+__device__ __forceinline__ float2 lane_nearest(const float2* __restrict__ pts, int o0, int o1, float x, float y,
+                                               float2* __restrict__ row, int lane) {
+    float bd = __builtin_inff();
+    float2 sp = make_float2(3.0e15f, 3.0e15f);
+    if (o1 <= o0) return sp;
+    const int last = o1 - 1;
+    float2 nxt = pts[min(o0 + lane, last)];
+    for (int p = o0; p < o1; p += WAVE) {
+        row[lane] = nxt;
+        if (p + WAVE < o1) nxt = pts[min(p + WAVE + lane, last)];
+        __builtin_amdgcn_wave_barrier();
+        const int cnt = min(WAVE, o1 - p);
+        int bl = -1;
+        auto group = [&](int u8) {
+            const float4* q = reinterpret_cast<const float4*>(row + u8);
+            const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+            const float d0 = dist2(x, y, q0.x, q0.y), d1 = dist2(x, y, q0.z, q0.w);
+            const float d2 = dist2(x, y, q1.x, q1.y), d3 = dist2(x, y, q1.z, q1.w);
+            const float d4 = dist2(x, y, q2.x, q2.y), d5 = dist2(x, y, q2.z, q2.w);
+            const float d6 = dist2(x, y, q3.x, q3.y), d7 = dist2(x, y, q3.z, q3.w);
+            const float m = fminf(fminf(fminf(fminf(d0, d1), d2), fminf(fminf(d3, d4), d5)), fminf(d6, d7));
+            const bool take = m < bd;
+            bd = take ? m : bd;
+            bl = take ? u8 : bl;
+        };
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        if (m) {
-            const int b = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            if (row == g) mine = b;
-            ++n_popped;
+        for (int u8 = 0; u8 < WAVE; u8 += 8)
+            if (u8 < cnt) group(u8);                                   // uniform
+        if (bl >= 0) {                                                 // this lane's minimum moved: which slot?
+            const float4* q = reinterpret_cast<const float4*>(row + bl);
+            const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+            sp = make_float2(q3.z, q3.w);
+            if (dist2(x, y, q3.x, q3.y) == bd) sp = make_float2(q3.x, q3.y);
+            if (dist2(x, y, q2.z, q2.w) == bd) sp = make_float2(q2.z, q2.w);
+            if (dist2(x, y, q2.x, q2.y) == bd) sp = make_float2(q2.x, q2.y);
+            if (dist2(x, y, q1.z, q1.w) == bd) sp = make_float2(q1.z, q1.w);
+            if (dist2(x, y, q1.x, q1.y) == bd) sp = make_float2(q1.x, q1.y);
+            if (dist2(x, y, q0.z, q0.w) == bd) sp = make_float2(q0.z, q0.w);
+            if (dist2(x, y, q0.x, q0.y) == bd) sp = make_float2(q0.x, q0.y);
         }
+        __builtin_amdgcn_wave_barrier();
     }
-    return mine;
+    return sp;
 }
 
 __device__ __forceinline__ uint32_t mix32(uint32_t a) {   // lowbias32
@@ -231,215 +227,224 @@ __device__ __forceinline__ float waypoint_coord(uint32_t seed, uint32_t ped, uin
     return (float)(h >> 8) * 5.9604644775390625e-08f * side;   // 2^-24
 }
 
-// A candidate list restricts which polylines a pedestrian tests: `list` (LDS, ascending polyline indices) holds
-// the polylines that can pass the cull for SOME pedestrian of the tile; null = all K.  The per-pedestrian
-// tests below are exact either way, so results do not depend on the list (only the time does).
-struct Cand {
-    const int* list;
-    int count;
-    __device__ __forceinline__ int at(int c) const { return list ? list[c] : c; }
-};
-
-// BorderForce._get_force for one pedestrian (forces.py:145-167), wave-cooperative.
-// Borders whose every point is provably farther than 40 ln2 * b (+ radius) contribute less than 2^-40 a each
-// and are not scanned: the bound is the distance to the chord first-last point minus the polyline's largest
-// deviation from that chord (exact for the straight config borders of obstacles.py:344-355).
-template <bool RAD>
-__device__ __forceinline__ void border_force(const TickArgs& a, const Cand cand, float xi, float yi, float ri, int lane,
-                                             float& fx, float& fy) {
-    const Geo& g = a.borders;
-    const int row = lane >> 4, gl = lane & 15;
-    float ax = 0.0f, ay = 0.0f, spx = 0.0f, spy = 0.0f;
-    int cnt = 0;
-    const float skip = a.border_skip > 0.0f ? a.border_skip + (RAD ? fmaxf(ri, 0.0f) : 0.0f) : __builtin_inff();
-    auto flush = [&]() {
-        if (lane < cnt) {
-            const float ddx = xi - spx, ddy = yi - spy;
-            const float d = sqrtf(fmaf(ddx, ddx, ddy * ddy));
-            const float inv = (d == 0.0f) ? 1.0f : 1.0f / d;               // stateutils.normalize zero guard
-            const float dist = RAD ? d - ri : d;                            // forces.py:160-161
-            const float mag = a.border_a * ex2(dist * a.border_nlb);        // a*exp(-dist/b), :163
-            ax = fmaf(ddx * inv, mag, ax);
-            ay = fmaf(ddy * inv, mag, ay);
-        }
-        cnt = 0;
-    };
-    // Pass 1 (no dependences between trips, so the loads pipeline): every lane tests its own candidates and
-    // remembers the survivors as bits (trip t <-> bit t).  Pass 2 walks the bits, four borders per wave trip.
-    for (int base = 0; base < cand.count; base += WAVE * 64) {
-        const int trips = min(64, (cand.count - base + WAVE - 1) / WAVE);
-        unsigned long long bits = 0ull;
-#pragma unroll 4
-        for (int t = 0; t < trips; ++t) {
-            const int cidx = base + t * WAVE + lane;
-            const int k = cand.at(min(cidx, cand.count - 1));
-            const float4 c = g.ctr[k];
-            const float ddx = xi - c.x, ddy = yi - c.y;
-            const bool keep = (cidx < cand.count) & (fmaf(ddx, ddx, ddy * ddy) < c.z);   // |x - center| < section_length, strict (:149-150)
-            bits |= (unsigned long long)keep << t;
-        }
-        // refine the (few) survivors of this lane with the chord bound
-        for (unsigned long long b = bits; b;) {
-            const int t = __ffsll((long long)b) - 1;
-            b &= b - 1;
-            const int k = cand.at(base + t * WAVE + lane);
-            const float4 s0 = g.seg[2 * k], s1 = g.seg[2 * k + 1];
-            const float px = xi - s0.x, py = yi - s0.y;
-            const float tt = fminf(fmaxf(fmaf(px, s0.z, py * s0.w) * s1.x, 0.0f), 1.0f);
-            const float qx = fmaf(-tt, s0.z, px), qy = fmaf(-tt, s0.w, py);
-            if (sqrtf(fmaf(qx, qx, qy * qy)) - s1.y > skip) bits &= ~(1ull << t);
-        }
-        for (int t = 0; t < trips; ++t) {
-            const int cb = base + t * WAVE;
-            unsigned long long m = __ballot((bits >> t) & 1ull);
-            while (m) {
-                int nb;
-                const int mine = pop4(m, row, nb);
-                int o0 = 0, o1 = 0;
-                if (mine >= 0) { const int kk = cand.at(cb + mine); o0 = g.off[kk]; o1 = g.off[kk + 1]; }
-                const float2 p = row_nearest(g.pts, o0, o1, xi, yi, gl);
-                const int src = ((lane - cnt) & 3) << 4;                        // any lane of row (lane - cnt)
-                const float sx = __shfl(p.x, src), sy = __shfl(p.y, src);
-                if (lane >= cnt && lane < cnt + nb) { spx = sx; spy = sy; }
-                cnt += nb;
-                if (cnt > WAVE - 4) flush();
-            }
-        }
-    }
-    flush();
-    fx = wave_sum(ax);
-    fy = wave_sum(ay);
-}
-
-// ObstacleForce._get_force for one pedestrian (forces.py:217-275), wave-cooperative.
-template <bool RAD>
-__device__ __forceinline__ void obstacle_force(const Geo& g, const Cand cand, const IxConst& c, bool moving, float xi,
-                                               float yi, float vxi, float vyi, float ri, int lane, float& fx, float& fy) {
-    const int row = lane >> 4, gl = lane & 15;
-    float gx = 0.0f, gy = 0.0f, gz = 0.0f, spx = 0.0f, spy = 0.0f, svx = 0.0f, svy = 0.0f;
-    int cnt = 0;
-    auto flush = [&]() {
-        if (lane < cnt) {
-            float unused;
-            moussaid<false, RAD, true>(c, spx - xi, spy - yi, 0.0f, vxi - svx, vyi - svy, 0.0f, ri, gx, gy, gz,
-                                       unused);
-        }
-        cnt = 0;
-    };
-    for (int cb = 0; cb < cand.count; cb += WAVE) {
-        const int cidx = cb + lane;
-        bool keep = false;
-        float4 ck = make_float4(0.f, 0.f, 0.f, 0.f);
-        int k = 0;
-        if (cidx < cand.count) {
-            k = cand.at(cidx);
-            ck = g.ctr[k];
-            const float ddx = xi - ck.x, ddy = yi - ck.y;
-            keep = fmaf(ddx, ddx, ddy * ddy) < c.thr2;                      // |x - c_k| < perception_threshold (:222-223)
-        }
-        unsigned long long m = __ballot(keep);
-        while (m) {
-            int nb;
-            const int mine = pop4(m, row, nb);
-            const int kk = __shfl(k, max(mine, 0));
-            int o0 = 0, o1 = 0;
-            if (mine >= 0) { o0 = g.off[kk]; o1 = g.off[kk + 1]; }
-            const float2 p = row_nearest(g.pts, o0, o1, xi, yi, gl);
-            // velocity of this row's obstacle (static obstacles: v = 0, forces.py:212-213)
-            const float ovx = moving ? __shfl(ck.z, max(mine, 0)) : 0.0f;
-            const float ovy = moving ? __shfl(ck.w, max(mine, 0)) : 0.0f;
-            const int src = ((lane - cnt) & 3) << 4;
-            const float sx = __shfl(p.x, src), sy = __shfl(p.y, src);
-            const float tvx = moving ? __shfl(ovx, src) : 0.0f, tvy = moving ? __shfl(ovy, src) : 0.0f;
-            if (lane >= cnt && lane < cnt + nb) { spx = sx; spy = sy; svx = tvx; svy = tvy; }
-            cnt += nb;
-            if (cnt > WAVE - 4) flush();
-        }
-    }
-    flush();
-    fx = c.negA * wave_sum(gx);
-    fy = c.negA * wave_sum(gy);
-}
-
 // ------------------------------------------------------------------------------------------------------
 // geometry forces: border + static + dynamic obstacles, one workgroup per tile of 64 pedestrians
 // ------------------------------------------------------------------------------------------------------
-// Per kept polyline the work is a short dependent chain (offsets -> points -> argmin butterfly -> exp), so this
-// phase is latency-bound; it gets its own kernel (many waves in flight) instead of riding in the pair kernels'
-// epilogues, depends only on the tick's input state, and leaves {fbx,fby,fsx,fsy,fdx,fdy} in geo[6][N_pad].
-// Culling is hierarchical: wave 0 first tests every polyline against the TILE's bounding box (grown by the
-// cull radius) and compacts the survivors, in index order, into an LDS candidate list; each pedestrian then
-// runs its exact tests on the candidates only.  Compact tiles (a crowd in spatial index order) shrink the list
-// by the ratio world area / neighbourhood area; a scrambled crowd keeps every polyline and loses nothing.
-constexpr int GEO_CAND_MAX = 2048;
-constexpr int GEO_WAVES = 16;                 // 4 pedestrians per wave: enough waves in flight to hide the load chains
+// One lane per pedestrian, polylines wave-uniform.  Two phases:
+//  1. find.  The polylines are dealt to the 16 waves by index (k mod 16).  A wave tests 64 of its polylines at
+//     once, one per lane (all loads of the trip in flight together), against the TILE's bounding box -- a superset
+//     of every pedestrian's own test -- and for each survivor, its parameters read out of the owning lane with
+//     v_readlane (no memory access), runs the reference's exact per-pedestrian tests lane-parallel (strict `<`,
+//     forces.py:149-150,222-223).  A polyline kept by at least one lane becomes a 64-byte item in the wave's LDS
+//     list.
+//  2. scan.  The items of all waves, in (wave, index) order, are dealt round-robin, so the expensive part balances
+//     whatever the find phase produced.  A wave re-derives the keep mask, scans the polyline once for all 64
+//     pedestrians (lane_nearest) and evaluates the force term in the lanes that kept it.
+// Per-wave partial sums meet in LDS in wave order; every assignment above is a function of the data only, so the
+// result is deterministic.  Compact tiles (a crowd in spatial index order) make the survivors few and the lanes
+// agree; a scrambled crowd keeps every polyline (list overflow: the finder scans on the spot) and only costs time.
+// Depends on the tick's input state only: runs beside the pair kernel on a side stream and leaves
+// {fbx,fby,fsx,fsy,fdx,fdy} in geo[6][N_pad].
+constexpr int GEO_WAVES = 16;
 constexpr int GEO_BLOCK = GEO_WAVES * WAVE;
+constexpr int GEO_ITEMS = 32;                  // list capacity per wave
 
-__device__ __forceinline__ int build_candidates(const Geo& g, bool borders, float thr2, float x0, float y0, float x1, float y1,
-                                                int lane, int* list) {
-    int n = 0;                                                       // uniform
-    for (int kb = 0; kb < g.K; kb += WAVE) {
-        const int k = kb + lane;
-        bool keep = false;
-        if (k < g.K) {
-            const float4 c = g.ctr[k];
-            const float gx = fmaxf(0.0f, fmaxf(x0 - c.x, c.x - x1)), gy = fmaxf(0.0f, fmaxf(y0 - c.y, c.y - y1));
-            // superset of the per-pedestrian test |x - c| < R: the box point nearest to c is at least as near
-            keep = fmaf(gx, gx, gy * gy) < (borders ? c.z : thr2);
-        }
-        const unsigned long long m = __ballot(keep);
-        const int pos = n + __popcll(m & ((1ull << lane) - 1ull));
-        n += __popcll(m);
-        if (n > GEO_CAND_MAX) return -1;                             // too many: caller falls back to all K
-        if (keep) list[pos] = k;
+struct GeoItem {
+    int o0, o1, kind, pad;                     // kind 0 border, 1 static, 2 dynamic obstacle
+    float4 c;                                  // borders {cx, cy, section_length^2, 0}; obstacles {cx, cy, vx, vy}
+    float4 s0, s1;                             // borders: chord {ax, ay, abx, aby}, {1/|ab|^2, max deviation, 0, 0}
+};
+
+struct GeoLane {                               // one pedestrian
+    float x, y, vx, vy, r, skip;
+    bool live, walk;
+};
+
+__device__ __forceinline__ float readlane(float v, int l) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+__device__ __forceinline__ float4 readlane(const float4 v, int l) {
+    return make_float4(readlane(v.x, l), readlane(v.y, l), readlane(v.z, l), readlane(v.w, l));
+}
+
+// the reference's own per-pedestrian cull for one polyline (plus, for borders, the 2^-40 chord bound)
+__device__ __forceinline__ bool geo_keep(const TickArgs& a, const GeoLane& me, int kind, const float4 c, const float4 s0,
+                                         const float4 s1) {
+    const float cdx = me.x - c.x, cdy = me.y - c.y;
+    const float d2 = fmaf(cdx, cdx, cdy * cdy);
+    if (kind == 0) {
+        // A border whose every point is provably farther than 40 ln2 * b (+ radius) contributes less than
+        // 2^-40 a: the bound is the distance to the chord first-last point minus the polyline's largest
+        // deviation from that chord (exact for the straight config borders of obstacles.py:344-355).
+        const float px = me.x - s0.x, py = me.y - s0.y;
+        const float tt = fminf(fmaxf(fmaf(px, s0.z, py * s0.w) * s1.x, 0.0f), 1.0f);
+        const float qx = fmaf(-tt, s0.z, px), qy = fmaf(-tt, s0.w, py);
+        return me.walk & (d2 < c.z) &                                 // |x - center| < section_length, strict (:149-150)
+               !(sqrtf(fmaf(qx, qx, qy * qy)) - s1.y > me.skip);
     }
-    return n;
+    return me.live & (d2 < (kind == 1 ? a.stat.thr2 : a.dyn.thr2));  // |x - c_k| < perception_threshold (:222-223)
+}
+
+// BorderForce._get_force (forces.py:145-167) / ObstacleForce._get_force (forces.py:217-275) for one polyline
+template <bool RAD>
+__device__ __forceinline__ void geo_item(const TickArgs& a, const GeoLane& me, const GeoItem& it, bool keep, float2* row,
+                                         int lane, float (&f)[6]) {
+    const Geo& g = it.kind == 0 ? a.borders : it.kind == 1 ? a.statics : a.dynamics;
+    const float2 sp = lane_nearest(g.pts, it.o0, it.o1, me.x, me.y, row, lane);
+    if (!keep) return;
+    if (it.kind == 0) {
+        const float ddx = me.x - sp.x, ddy = me.y - sp.y;
+        const float d = sqrtf(fmaf(ddx, ddx, ddy * ddy));
+        const float inv = (d == 0.0f) ? 1.0f : 1.0f / d;                       // stateutils.normalize zero guard
+        const float dist = RAD ? d - me.r : d;                                  // forces.py:160-161
+        const float mag = a.border_a * ex2(dist * a.border_nlb);                // a*exp(-dist/b), :163
+        f[0] = fmaf(ddx * inv, mag, f[0]);
+        f[1] = fmaf(ddy * inv, mag, f[1]);
+    } else {
+        const bool moving = it.kind == 2;                                       // static obstacles: v = 0 (:212-213)
+        const float ovx = moving ? it.c.z : 0.0f, ovy = moving ? it.c.w : 0.0f;
+        float gx = 0.f, gy = 0.f, gz = 0.f, unused;
+        moussaid<false, RAD, true>(moving ? a.dyn : a.stat, sp.x - me.x, sp.y - me.y, 0.0f, me.vx - ovx, me.vy - ovy, 0.0f,
+                                   me.r, gx, gy, gz, unused);
+        if (moving) { f[4] += gx; f[5] += gy; } else { f[2] += gx; f[3] += gy; }
+    }
+}
+
+// The tile's view of the geometry: bounding box of its pedestrians, centre / half diagonal, largest chord skip.
+struct GeoTile { float x0, y0, x1, y1, cx, cy, half_diag, skip_max; };
+
+// One pass of a wave over its polylines (k = base + 16 lane + wave).  64 at a time, one per lane, they are tested
+// against the tile; each survivor's parameters are read out of its lane with v_readlane and the reference's exact
+// per-pedestrian test runs lane-parallel.  SCAN = false: the first GEO_ITEMS kept polylines go to the wave's list;
+// returns how many were kept.  SCAN = true (list overflow): the kept polylines beyond GEO_ITEMS are scanned on the spot.
+template <bool RAD, bool SCAN>
+__device__ __forceinline__ int geo_find(const TickArgs& a, const GeoLane& me, const GeoTile& tb, GeoItem* list, float2* row,
+                                        int lane, int wave, float (&f)[6]) {
+    int n_found = 0;                                                   // uniform
+#pragma unroll
+    for (int kind = 0; kind < 3; ++kind) {
+        const Geo& g = kind == 0 ? a.borders : kind == 1 ? a.statics : a.dynamics;
+        if (!(kind == 0 ? a.en_border : kind == 1 ? a.en_static : a.en_dynamic)) continue;
+        const float thr2 = kind == 1 ? a.stat.thr2 : a.dyn.thr2;
+        for (int base = 0; base < g.K; base += GEO_BLOCK) {
+            const int k = base + lane * GEO_WAVES + wave;
+            bool near = false;
+            float4 c = make_float4(0.f, 0.f, 0.f, 0.f), s0 = c, s1 = c;
+            int o0 = 0, o1 = 0;
+            if (k < g.K) {
+                c = g.ctr[k];
+                o0 = g.off[k]; o1 = g.off[k + 1];
+                // the box point nearest to the centre is at least as near as any pedestrian of the tile
+                const float gx = fmaxf(0.0f, fmaxf(tb.x0 - c.x, c.x - tb.x1)), gy = fmaxf(0.0f, fmaxf(tb.y0 - c.y, c.y - tb.y1));
+                near = fmaf(gx, gx, gy * gy) < (kind == 0 ? c.z : thr2);
+                if (kind == 0) {
+                    s0 = g.seg[2 * k]; s1 = g.seg[2 * k + 1];
+                    // no pedestrian is nearer to the chord than the box centre is, minus the half diagonal
+                    const float px = tb.cx - s0.x, py = tb.cy - s0.y;
+                    const float tt = fminf(fmaxf(fmaf(px, s0.z, py * s0.w) * s1.x, 0.0f), 1.0f);
+                    const float qx = fmaf(-tt, s0.z, px), qy = fmaf(-tt, s0.w, py);
+                    near &= !(sqrtf(fmaf(qx, qx, qy * qy)) - tb.half_diag - s1.y > tb.skip_max);
+                }
+            }
+            unsigned long long m = __ballot(near);
+            while (m) {
+                const int b = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                GeoItem it;
+                it.o0 = __builtin_amdgcn_readlane(o0, b); it.o1 = __builtin_amdgcn_readlane(o1, b);
+                it.kind = kind; it.pad = 0;
+                it.c = readlane(c, b);
+                it.s0 = kind == 0 ? readlane(s0, b) : make_float4(0.f, 0.f, 0.f, 0.f);
+                it.s1 = kind == 0 ? readlane(s1, b) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const bool keep = geo_keep(a, me, kind, it.c, it.s0, it.s1);
+                if (!__any(keep)) continue;
+                if (SCAN) {
+                    if (n_found >= GEO_ITEMS) geo_item<RAD>(a, me, it, keep, row, lane, f);
+                } else if (n_found < GEO_ITEMS && lane == 0) {
+                    list[n_found] = it;
+                }
+                ++n_found;
+            }
+        }
+    }
+    return n_found;
 }
 
 template <bool RAD>
 __global__ __launch_bounds__(GEO_BLOCK) void sfm_geometry_kernel(const TickArgs a) {
-    __shared__ int s_list[3][GEO_CAND_MAX];
-    __shared__ int s_count[3];
+    __shared__ float2 s_row[GEO_WAVES][WAVE];
+    __shared__ float s_acc[GEO_WAVES][6][WAVE];
+    __shared__ GeoItem s_item[GEO_WAVES][GEO_ITEMS];
+    __shared__ int s_count[GEO_WAVES];
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = uniform((int)(threadIdx.x >> 6));
     const int t = (a.i_begin >> 6) + blockIdx.x;                      // tile index
     const int p0 = max(a.i_begin, t * WAVE), p1 = min(a.i_end, (t + 1) * WAVE);
-    const bool want_b = a.en_border && a.borders.K > 0, want_s = a.en_static && a.statics.K > 0,
-               want_d = a.en_dynamic && a.dynamics.K > 0;
-    if (wave == 0) {
-        const int i = p0 + lane;
-        const float inf = __builtin_inff();
-        float x0 = inf, y0 = inf, x1 = -inf, y1 = -inf;
-        if (i < p1) { const float4 s = a.pk_cur[i]; x0 = x1 = s.x; y0 = y1 = s.y; }
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) {
-            x0 = fminf(x0, __shfl_xor(x0, m)); y0 = fminf(y0, __shfl_xor(y0, m));
-            x1 = fmaxf(x1, __shfl_xor(x1, m)); y1 = fmaxf(y1, __shfl_xor(y1, m));
-        }
-        const int nb = want_b ? build_candidates(a.borders, true, 0.f, x0, y0, x1, y1, lane, s_list[0]) : 0;
-        const int ns = want_s ? build_candidates(a.statics, false, a.stat.thr2, x0, y0, x1, y1, lane, s_list[1]) : 0;
-        const int nd = want_d ? build_candidates(a.dynamics, false, a.dyn.thr2, x0, y0, x1, y1, lane, s_list[2]) : 0;
-        if (lane == 0) { s_count[0] = nb; s_count[1] = ns; s_count[2] = nd; }
-    }
-    __syncthreads();
-    const Cand cb{s_count[0] >= 0 ? s_list[0] : nullptr, s_count[0] >= 0 ? s_count[0] : a.borders.K};
-    const Cand cs{s_count[1] >= 0 ? s_list[1] : nullptr, s_count[1] >= 0 ? s_count[1] : a.statics.K};
-    const Cand cd{s_count[2] >= 0 ? s_list[2] : nullptr, s_count[2] >= 0 ? s_count[2] : a.dynamics.K};
-    for (int i = p0 + wave; i < p1; i += GEO_WAVES) {
+    const int i = t * WAVE + lane;
+    GeoLane me;
+    me.live = i >= p0 && i < p1;
+    me.x = 3.0e15f; me.y = 3.0e15f; me.vx = 0.f; me.vy = 0.f; me.r = 0.f;
+    if (me.live) {
         const float4 s = a.pk_cur[i];
-        const float x = uniform(s.x), y = uniform(s.y), vx = uniform(s.z), vy = uniform(s.w);
-        const float r = uniform(a.own[i].w);
-        float fbx = 0.f, fby = 0.f, fsx = 0.f, fsy = 0.f, fdx = 0.f, fdy = 0.f;
-        if (want_b && cb.count > 0 && !(a.crossing && a.crossing[i]))    // forces.py:140-141,176-177
-            border_force<RAD>(a, cb, x, y, r, lane, fbx, fby);
-        if (want_s && cs.count > 0)
-            obstacle_force<RAD>(a.statics, cs, a.stat, false, x, y, vx, vy, r, lane, fsx, fsy);
-        if (want_d && cd.count > 0)
-            obstacle_force<RAD>(a.dynamics, cd, a.dyn, true, x, y, vx, vy, r, lane, fdx, fdy);
-        if (lane < 6) {
-            const float v = lane == 0 ? fbx : lane == 1 ? fby : lane == 2 ? fsx : lane == 3 ? fsy : lane == 4 ? fdx : fdy;
-            a.geo[(size_t)lane * a.N_pad + i] = v;
+        me.x = s.x; me.y = s.y; me.vx = s.z; me.vy = s.w;
+        me.r = a.own[i].w;
+    }
+    const float inf = __builtin_inff();
+    me.walk = me.live && !(a.crossing && a.crossing[i]);              // forces.py:140-141,176-177
+    me.skip = a.border_skip > 0.0f ? a.border_skip + (RAD ? fmaxf(me.r, 0.0f) : 0.0f) : inf;
+    // the tile's bounding box; parked (despawned) pedestrians sit ~3e15 m away, no cull can keep them
+    const bool inbox = me.live && fabsf(me.x) < 1.0e12f && fabsf(me.y) < 1.0e12f;
+    float x0 = inbox ? me.x : inf, y0 = inbox ? me.y : inf, x1 = inbox ? me.x : -inf, y1 = inbox ? me.y : -inf;
+    float skip_max = me.live ? me.skip : 0.0f;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        x0 = fminf(x0, __shfl_xor(x0, m)); y0 = fminf(y0, __shfl_xor(y0, m));
+        x1 = fmaxf(x1, __shfl_xor(x1, m)); y1 = fmaxf(y1, __shfl_xor(y1, m));
+        skip_max = fmaxf(skip_max, __shfl_xor(skip_max, m));
+    }
+    GeoTile tb;
+    tb.x0 = x0; tb.y0 = y0; tb.x1 = x1; tb.y1 = y1;
+    tb.cx = 0.5f * (x0 + x1); tb.cy = 0.5f * (y0 + y1);
+    const float hx = 0.5f * (x1 - x0), hy = 0.5f * (y1 - y0);
+    tb.half_diag = sqrtf(fmaf(hx, hx, hy * hy)) * 1.0001f + 1.0e-3f;
+    tb.skip_max = skip_max;
+    float2* row = s_row[wave];
+    float f[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    // ---- phase 1: find
+    const int n_found = geo_find<RAD, false>(a, me, tb, s_item[wave], row, lane, wave, f);
+    if (lane == 0) s_count[wave] = min(n_found, GEO_ITEMS);
+    __syncthreads();
+
+    // ---- phase 2: scan, items dealt round-robin in (wave, index) order
+    {
+        int w = 0, first = 0, cnt = s_count[0];                       // items [first, first + cnt) belong to list w
+        int total = 0;
+#pragma unroll
+        for (int q = 0; q < GEO_WAVES; ++q) total += s_count[q];
+        total = uniform(total);
+        for (int j = wave; j < total; j += GEO_WAVES) {
+            while (j >= first + cnt) { first += cnt; ++w; cnt = s_count[w]; }
+            const GeoItem it = s_item[uniform(w)][uniform(j - first)];
+            GeoItem u = it;
+            u.o0 = uniform(it.o0); u.o1 = uniform(it.o1); u.kind = uniform(it.kind);
+            const bool keep = geo_keep(a, me, u.kind, u.c, u.s0, u.s1);
+            geo_item<RAD>(a, me, u, keep, row, lane, f);
         }
+    }
+    // ---- list overflow (a tile whose pedestrians are spread over the whole map): this wave walks its polylines
+    // again and scans, on the spot, the kept ones that did not fit
+    if (n_found > GEO_ITEMS) geo_find<RAD, true>(a, me, tb, s_item[wave], row, lane, wave, f);
+#pragma unroll
+    for (int q = 0; q < 6; ++q) s_acc[wave][q][lane] = f[q];
+    __syncthreads();
+    if (wave < 6 && me.live) {                                         // wave w finishes component w
+        float v = 0.0f;
+#pragma unroll
+        for (int w = 0; w < GEO_WAVES; ++w) v += s_acc[w][wave][lane];
+        if (wave >= 4) v *= a.dyn.negA;
+        else if (wave >= 2) v *= a.stat.negA;
+        a.geo[(size_t)wave * a.N_pad + i] = v;
     }
 }
 
@@ -967,7 +972,8 @@ __global__ __launch_bounds__(BLOCK) void sfm_pair_sym_kernel(const float4* __res
     }
     if (sa.debug_steps >= 0) nsteps = sa.debug_steps;
 
-    float fxi = 0.f, fyi = 0.f, fxj = 0.f, fyj = 0.f, flag = 0.f;
+    float fxi = 0.f, fyi = 0.f, fxj = 0.f, fyj = 0.f;
+    int flag = 0;                                  // max of the bit patterns of rsq(d2) (positive floats order like ints)
     int i_end_loc = lane;
     if (ta >= 0) {
         const float4 pj = pk[tb * WAVE + lane];
@@ -987,7 +993,7 @@ __global__ __launch_bounds__(BLOCK) void sfm_pair_sym_kernel(const float4* __res
         auto step = [&](bool both) {
             float cx = 0.f, cy = 0.f, cz = 0.f, rinv;
             moussaid<false, false, false>(c, pj.x - xi, pj.y - yi, 0.f, vxi - pj.z, vyi - pj.w, 0.f, 0.f, cx, cy, cz, rinv);
-            flag = fmaxf(flag, rinv);
+            flag = max(flag, __float_as_int(rinv));
             fxi += cx;
             fyi += cy;
             if (both) { fxj -= cx; fyj -= cy; }
@@ -1004,8 +1010,8 @@ __global__ __launch_bounds__(BLOCK) void sfm_pair_sym_kernel(const float4* __res
             for (int s = 0; s < nsteps; ++s) step(true);
         }
         i_end_loc = (lane + sa.dir * (sig0 + nsteps)) & (WAVE - 1);
-        flag = wave_max(flag);
-        if (flag >= COINCIDENT_RINV && lane == 0) { sa.tile_flag[ta] = 1; sa.tile_flag[tb] = 1; }
+        const float fmax_ = wave_max(__int_as_float(flag));
+        if (fmax_ >= COINCIDENT_RINV && lane == 0) { sa.tile_flag[ta] = 1; sa.tile_flag[tb] = 1; }
     }
     s_fi[wave][i_end_loc] = make_float2(fxi, fyi);
     s_fj[wave][lane] = make_float2(fxj, fyj);

@@ -1,10 +1,15 @@
 // sfm_reorder.hip -- periodic spatial re-sort of the pedestrian rows on the device.
 //
-// The cutoff of sfm_kernels.hip (tiles_negligible) only pays while 64-row tiles are spatially compact.
-// sfm_upload_state puts the rows in Hilbert order once; pedestrians then walk ~0.06 m per tick, so a
-// device-resident run re-sorts every few dozen ticks: keys (Hilbert-curve index of the 1 m cell) -> stable radix sort of
-// (key, row) with rocPRIM -> gather of every per-row array.  A pure function of the state, so it is
-// deterministic; despawned pedestrians (parked far away) sort to the end.
+// The tile cutoff (tiles_negligible) and the geometry kernel's tile-level culling only pay while every 64-row tile
+// is a compact patch.  Row order is "sort-tile-recursive" packing: sort by x, cut the ranking into strips of
+// `strip_rows` rows (a multiple of 64, about sqrt(#tiles) tiles each), sort every strip by y.  Each tile is then
+// exactly the 64 pedestrians of one axis-aligned rectangle (strip width x a run in y): no L-shaped or split tiles,
+// whatever the density, and no padding rows.  (A space-filling-curve order gives tiles that straddle two or three
+// curve blocks as soon as the counts stop lining up with powers of two: 2-3x larger boxes on an evolved crowd.)
+// sfm_upload_state packs once on the host; pedestrians then walk ~0.06 m per tick, so a device-resident run
+// re-packs every few dozen ticks: two rocPRIM radix sorts + a gather of every per-row array.  A pure function of
+// the state (stable sorts, ties by row), so it is deterministic; despawned pedestrians (parked ~3e15 m away) sort
+// into the last strip.
 #include "sfm_device.h"
 
 #include <cstring>
@@ -12,32 +17,26 @@
 
 namespace sfm {
 
-// Position along the Hilbert curve of the 65536 x 65536 grid of 1 m cells.  Unlike the Z-order curve it has no
-// jumps: any 64 consecutive pedestrians along it occupy one compact patch, so fixed 64-row tiles have small
-// bounding boxes wherever the tile boundaries fall.  (Same routine on the host in sfm_capi.hip.)
-__host__ __device__ inline uint32_t hilbert_key(uint32_t x, uint32_t y) {
-    uint32_t d = 0;
-    for (uint32_t s = 32768u; s > 0; s >>= 1) {
-        const uint32_t rx = (x & s) ? 1u : 0u, ry = (y & s) ? 1u : 0u;
-        d += s * s * ((3u * rx) ^ ry);
-        if (ry == 0) {
-            if (rx == 1) { x = 65535u - x; y = 65535u - y; }
-            const uint32_t t = x; x = y; y = t;
-        }
-    }
-    return d;
+// order-preserving map float -> uint32 (NaN after +inf).  Same routine on the host in sfm_capi.hip.
+__host__ __device__ inline uint32_t float_key(float v) {
+    uint32_t b;
+    memcpy(&b, &v, sizeof(b));
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
 }
 
-__global__ void sfm_cell_keys_kernel(const float4* __restrict__ pk, int N, float x0, float y0, uint32_t* __restrict__ key,
-                                       uint32_t* __restrict__ row) {
+__global__ void sfm_x_keys_kernel(const float4* __restrict__ pk, int N, uint32_t* __restrict__ key, uint32_t* __restrict__ row) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= N) return;
-    const float4 p = pk[s];
-    const float fx = p.x - x0, fy = p.y - y0;
-    const uint32_t cx = (fx >= 0.f && fx < 65535.f) ? (uint32_t)fx : (fx < 0.f ? 0u : 65535u);
-    const uint32_t cy = (fy >= 0.f && fy < 65535.f) ? (uint32_t)fy : (fy < 0.f ? 0u : 65535u);
-    key[s] = (fabsf(p.x) < 1.0e14f) ? hilbert_key(cx, cy) : 0xffffffffu;   // parked ghosts last
+    key[s] = float_key(pk[s].x);
     row[s] = (uint32_t)s;
+}
+
+// rank r of the x order -> key (strip, y)
+__global__ void sfm_strip_keys_kernel(const float4* __restrict__ pk, int N, int strip_rows, const uint32_t* __restrict__ row,
+                                      unsigned long long* __restrict__ key) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= N) return;
+    key[r] = ((unsigned long long)(uint32_t)(r / strip_rows) << 32) | float_key(pk[row[r]].y);
 }
 
 __global__ void sfm_gather_rows_kernel(const uint32_t* __restrict__ src, int N, const float4* __restrict__ pk_in,
@@ -60,25 +59,36 @@ __global__ void sfm_gather_rows_kernel(const uint32_t* __restrict__ src, int N, 
 }
 
 struct ReorderBufs {
-    uint32_t *key_in, *key_out, *row_in, *row_out;
+    unsigned long long *key64_in, *key64_out;
+    uint32_t *row_a, *row_b, *key32_in, *key32_out;   // the final order is in row_b: row_b[s] = old row that moves to row s
     void* temp;
     size_t temp_bytes;
 };
 
 size_t reorder_temp_bytes(int N) {
-    size_t bytes = 0;
+    size_t b32 = 0, b64 = 0;
     uint32_t* p = nullptr;
-    rocprim::radix_sort_pairs(nullptr, bytes, p, p, p, p, (size_t)N, 0, 32, nullptr);
-    return bytes;
+    unsigned long long* q = nullptr;
+    rocprim::radix_sort_pairs(nullptr, b32, p, p, p, p, (size_t)N, 0, 32, nullptr);
+    rocprim::radix_sort_pairs(nullptr, b64, q, q, p, p, (size_t)N, 0, 64, nullptr);
+    return b32 > b64 ? b32 : b64;
 }
 
-// keys -> sort -> row_out[s] = old row that moves to row s
-hipError_t launch_resort(const float4* pk, int N, float x0, float y0, const ReorderBufs& b, hipStream_t st) {
-    hipLaunchKernelGGL(sfm_cell_keys_kernel, dim3((N + 255) / 256), dim3(256), 0, st, pk, N, x0, y0, b.key_in, b.row_in);
+hipError_t launch_resort(const float4* pk, int N, int strip_rows, const ReorderBufs& b, hipStream_t st) {
+    const dim3 grid((N + 255) / 256), block(256);
+    hipLaunchKernelGGL(sfm_x_keys_kernel, grid, block, 0, st, pk, N, b.key32_in, b.row_b);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     size_t bytes = b.temp_bytes;
-    return rocprim::radix_sort_pairs(b.temp, bytes, b.key_in, b.key_out, b.row_in, b.row_out, (size_t)N, 0, 32, st);
+    e = rocprim::radix_sort_pairs(b.temp, bytes, b.key32_in, b.key32_out, b.row_b, b.row_a, (size_t)N, 0, 32, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(sfm_strip_keys_kernel, grid, block, 0, st, pk, N, strip_rows, b.row_a, b.key64_in);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    int strip_bits = 1;
+    while (((N + strip_rows - 1) / strip_rows) >> strip_bits) ++strip_bits;
+    bytes = b.temp_bytes;
+    return rocprim::radix_sort_pairs(b.temp, bytes, b.key64_in, b.key64_out, b.row_a, b.row_b, (size_t)N, 0, 32 + strip_bits, st);
 }
 
 hipError_t launch_gather(const uint32_t* src, int N, const float4* pk_in, float4* pk_out, const float2* zv_in, float2* zv_out,

@@ -182,6 +182,44 @@ def test_radius_and_z_variants_vs_oracle(variant, reorder, monkeypatch):
         eng.close()
 
 
+@pytest.mark.parametrize("use_radius", [False, True])
+def test_dense_geometry_overflows_the_per_wave_lists(use_radius):
+    """A small square packed with polylines: every wave of the geometry kernel keeps more polylines than its LDS
+    list holds (32), so the on-the-spot scan of the overflow pass and the list path both contribute."""
+    n = 200
+    sc = scenarios.make_scenario(n, 4242, n_borders=900, n_static=700, n_dynamic=40, border_len=(4.0, 12.0))
+    cfg = default_sfm_config()
+    cfg["use_ped_radius"] = use_radius
+    prm = O.OracleParams.from_config(cfg)
+    geom = O.Geometry(sc.borders, sc.border_centers, sc.border_lengths, sc.static_obstacles, sc.dynamic_obstacles,
+                      sc.dynamic_vel)
+    diag = {}
+    with np.errstate(all="ignore"):
+        per, total, _ = O.tick_forces(sc.loc, sc.vel, sc.waypoint, sc.target_speed, sc.radius, np.zeros(n, bool), geom,
+                                      prm, theta_tol=P.THETA_TOL, tie_rel=P.TIE_REL, diag=diag)
+    # the premise: some pedestrian keeps far more static obstacles than 16 waves x 32 slots / (its share)
+    kept = (np.linalg.norm(sc.loc[:, None, :2] - np.array([c for c, _ in sc.static_obstacles])[None], axis=2) < 20.0).any(0)
+    assert kept.sum() > 16 * 32
+    v_new = O.new_velocities(sc.vel, total, sc.target_speed, 0.05)
+    eng = SfmEngine(cfg, 0.05)
+    try:
+        eng.set_borders(sc.borders, sc.border_centers, sc.border_lengths)
+        eng.set_static_obstacles(sc.static_obstacles)
+        eng.set_dynamic_obstacles(sc.dynamic_obstacles, sc.dynamic_vel)
+        eng.upload_state(sc.loc, sc.vel, sc.waypoint, sc.target_speed, sc.radius, None)
+        eng.tick(record=True)
+        for name in O.FORCE_NAMES:
+            P.check_force(name, eng.forces(name), per[name], diag[name][1], diag[name][0])
+        # Hundreds of obstacle terms of opposite directions per pedestrian: |F| is far below the sum of the
+        # magnitudes, so v' = cap(v + dt F) inherits dt * 1e-5 * (that sum), not 1e-5 |v'|.  Stated here, used only here.
+        got, ref = np.asarray(eng.velocities(), dtype=np.float64), v_new
+        summed = sum(np.nan_to_num(diag[name][1]) for name in O.FORCE_NAMES)
+        allow = P.RTOL * (np.linalg.norm(ref, axis=1) + 0.05 * summed) + 0.05 * np.nan_to_num(diag["total"][0]) * 1.001 + 1e-12
+        assert (np.linalg.norm(got - ref, axis=1) <= allow).all()
+    finally:
+        eng.close()
+
+
 def test_property_checks_at_baseline_size():
     """BASELINE config 2 at full size (N=4096): properties the math implies, plus a
     row-sampled comparison against the C oracle."""

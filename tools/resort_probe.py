@@ -1,0 +1,24 @@
+"""Diagnostic: geometry / pair kernel time along a c3 run, (a) with the periodic device re-sort, (b) without it,
+(c) with a host re-upload (= host-side Hilbert sort) every 64 ticks instead.  Run under rocprofv3 --kernel-trace."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from carla_social_force_model_amd import scenarios
+from carla_social_force_model_amd.config import default_sfm_config
+from carla_social_force_model_amd.stepper import HipShardEngine
+mode = sys.argv[1]
+sc, forces = scenarios.baseline_scenario("c3")
+if mode in ("none", "host"):
+    os.environ["SFM_RESORT_EVERY"] = "0"
+eng = HipShardEngine(default_sfm_config(forces), 0.05)
+eng.load(sc)
+for block in range(4):
+    eng.run(64)
+    eng.synchronize()
+    if mode == "host":
+        e = eng.engine
+        loc, vel, wp = e.state()
+        wp3 = np.zeros_like(loc); wp3[:, :2] = wp
+        e.upload_state(loc, vel, wp3, sc.target_speed, sc.radius, None)
+eng.close()

@@ -30,6 +30,20 @@ __global__ void k(float* out, int iters, float seed, unsigned long long* stamps)
         } else if (OP == 5) {  // v_cmp + v_cndmask (select) x8
             a0 = a0 > d ? a1 : a0; a1 = a1 > d ? a2 : a1; a2 = a2 > d ? a3 : a2; a3 = a3 > d ? a4 : a3;
             a4 = a4 > d ? a5 : a4; a5 = a5 > d ? a6 : a5; a6 = a6 > d ? a7 : a6; a7 = a7 > d ? a0 : a7;
+        } else if (OP == 7 || OP == 8 || OP == 9) {  // DPP moves: wave_rol:1 / row_ror:1 / quad_perm
+            constexpr int ctrl = OP == 7 ? 0x134 : (OP == 8 ? 0x121 : 0xB1);
+#define ROT(v) v = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), ctrl, 0xf, 0xf, false))
+            ROT(a0); ROT(a1); ROT(a2); ROT(a3); ROT(a4); ROT(a5); ROT(a6); ROT(a7);
+#undef ROT
+        } else if (OP == 10) {  // ds_bpermute (LDS crossbar) x8
+            const int idx = ((threadIdx.x + 1) & 63) << 2;
+            a0 = __int_as_float(__builtin_amdgcn_ds_bpermute(idx, __float_as_int(a0))); a1 = __int_as_float(__builtin_amdgcn_ds_bpermute(idx, __float_as_int(a1)));
+            a2 = __int_as_float(__builtin_amdgcn_ds_bpermute(idx, __float_as_int(a2))); a3 = __int_as_float(__builtin_amdgcn_ds_bpermute(idx, __float_as_int(a3)));
+            a4 = __int_as_float(__builtin_amdgcn_ds_bpermute(idx, __float_as_int(a4))); a5 = __int_as_float(__builtin_amdgcn_ds_bpermute(idx, __float_as_int(a5)));
+            a6 = __int_as_float(__builtin_amdgcn_ds_bpermute(idx, __float_as_int(a6))); a7 = __int_as_float(__builtin_amdgcn_ds_bpermute(idx, __float_as_int(a7)));
+        } else if (OP == 11) {  // v_fmaak (literal constant) x8
+            a0 = fmaf(a0, a1, 0.12345f); a1 = fmaf(a1, a2, 0.22345f); a2 = fmaf(a2, a3, 0.32345f); a3 = fmaf(a3, a4, 0.42345f);
+            a4 = fmaf(a4, a5, 0.52345f); a5 = fmaf(a5, a6, 0.62345f); a6 = fmaf(a6, a7, 0.72345f); a7 = fmaf(a7, a0, 0.82345f);
         } else if (OP == 6) {  // mixed: 4 fma + 4 exp interleaved
             a0 = fmaf(a0, c, d); a1 = __builtin_amdgcn_exp2f(a1); a2 = fmaf(a2, c, d); a3 = __builtin_amdgcn_exp2f(a3);
             a4 = fmaf(a4, c, d); a5 = __builtin_amdgcn_exp2f(a5); a6 = fmaf(a6, c, d); a7 = __builtin_amdgcn_exp2f(a7);
@@ -43,7 +57,7 @@ template <int OP>
 int run(const char* name, int waves_per_simd, float lanes_per_inst) {
     const int blocks = 256 * waves_per_simd;  // 256 threads = 4 waves -> one wave per SIMD per block per CU
     float* out; CHECK(hipMalloc(&out, sizeof(float) * blocks * 256));
-    const int iters = 400000;
+    const int iters = 100000;
     unsigned long long* stamps; CHECK(hipMalloc(&stamps, 16));
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, out, 100, 0.001f, stamps);
@@ -65,6 +79,7 @@ int main() {
     for (int w : {4, 8}) {
         run<0>("v_fma_f32", w, 1); run<1>("v_pk_fma_f32", w, 2); run<4>("v_pk_mul_f32", w, 2); run<2>("v_exp_f32", w, 1);
         run<3>("v_rsq_f32", w, 1); run<5>("cmp+cndmask", w, 1); run<6>("fma+exp mix", w, 1);
+        run<7>("dpp wave_rol:1", w, 1); run<8>("dpp row_ror:1", w, 1); run<9>("dpp quad_perm", w, 1); run<10>("ds_bpermute", w, 1); run<11>("v_fmaak lit", w, 1);
     }
     return 0;
 }
