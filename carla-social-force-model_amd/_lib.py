@@ -74,6 +74,8 @@ SYMBOLS = {
     "sfm_download_draw_counts": (C.c_int, [_H, _U32]),
     "sfm_packed_state_ptr": (C.c_void_p, [_H, C.POINTER(C.c_int)]),
     "sfm_packed_z_ptr": (C.c_void_p, [_H]),
+    "sfm_row_data_ptr": (C.c_void_p, [_H, C.c_int, C.POINTER(C.c_int)]),
+    "sfm_resort": (C.c_int, [_H]),
     "sfm_last_error": (C.c_char_p, [_H]),
     "sfm_get_timing": (C.c_int, [_H, C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "sfm_profile_dominant_kernel": (C.c_int, [_H, C.c_int, C.POINTER(C.c_float)]),

@@ -736,7 +736,19 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags) {
     h->ipw_last = ipw;
     // symmetric path: whole crowd on this handle, planar, no radius; auto mode wants >= 4 tiles
     const size_t need = (size_t)h->n_t * (size_t)h->n_t * WAVE;
-    const bool sym = !h->z3 && !h->rad && h->i_begin == 0 && h->i_end == h->N && h->slab && need <= h->slab_cap &&
+    bool order_pays, list_cut;                      // compact tiles only matter to the tile cutoff and the geometry kernel
+    {
+        TickArgs probe;
+        fill_args(h, probe, flags);
+        order_pays = probe.geo != nullptr || probe.tile_box != nullptr;
+        list_cut = probe.tile_box != nullptr && probe.tile_box_out == nullptr;
+    }
+    // a shard can use it too when its rows are whole tiles and the tile-pair list is on: pairs with a tile of another
+    // rank are then evaluated one-sided by both ranks
+    const bool whole = h->i_begin == 0 && h->i_end == h->N;
+    const bool tile_shard = n_local > 0 && (h->i_begin % WAVE) == 0 && ((h->i_end % WAVE) == 0 || h->i_end == h->N) && list_cut &&
+                            h->n_t < 32768;
+    const bool sym = !h->z3 && !h->rad && (whole || tile_shard) && h->slab && need <= h->slab_cap &&
                      h->dpp_dir != 0 && h->prm.enabled[SFM_FORCE_PEDESTRIAN] &&
                      (h->sym_mode == 1 || (h->sym_mode < 0 && h->N >= 256));
     h->used_sym = sym;
@@ -745,12 +757,6 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags) {
                   h->rad ? "true" : "false", team);
     HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
     int launches = 0;
-    bool order_pays;                                // compact tiles only matter to the tile cutoff and the geometry kernel
-    {
-        TickArgs probe;
-        fill_args(h, probe, flags);
-        order_pays = probe.geo != nullptr || probe.tile_box != nullptr;
-    }
     for (int t = 0; t < ticks; ++t) {
         if (h->reordered && h->resort_every > 0 && (flags & SFM_TICK_INTEGRATE) && h->i_begin == 0 && h->i_end == h->N &&
             h->ticks_since_sort >= h->resort_every && order_pays) {
@@ -787,7 +793,8 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags) {
         if (sym) {
             SymArgs sa{h->slab, h->tile_flag, h->n_t, h->n_t * WAVE, h->dpp_dir, getenv("SFM_DEBUG_STEPS") ? atoi(getenv("SFM_DEBUG_STEPS")) : -1,
                        (a.tile_box && !lite) ? h->work : nullptr, (a.tile_box && !lite) ? h->work_count : nullptr,
-                       lite ? a.tile_box : nullptr, lite ? a.tile_vmax : nullptr, a.cut_scale, a.cut_pad, h->stamps};
+                       lite ? a.tile_box : nullptr, lite ? a.tile_vmax : nullptr, a.cut_scale, a.cut_pad, h->stamps,
+                       h->i_begin / WAVE, (h->i_end + WAVE - 1) / WAVE};
             if (sa.work) launches += 1;
             HIP_TRY(h, launch_sym_pair(a, sa, h->stream));
             if (fork) HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
@@ -834,7 +841,7 @@ int sfm_profile_dominant_kernel(SfmHandle* h, int reps, float* avg_us) {
     const bool lite = a.tile_box_out != nullptr;
     SymArgs sa{h->slab, h->tile_flag, h->n_t, h->n_t * WAVE, h->dpp_dir, -1, (a.tile_box && !lite) ? h->work : nullptr,
                (a.tile_box && !lite) ? h->work_count : nullptr, lite ? a.tile_box : nullptr, lite ? a.tile_vmax : nullptr,
-               a.cut_scale, a.cut_pad, nullptr};
+               a.cut_scale, a.cut_pad, nullptr, h->i_begin / WAVE, (h->i_end + WAVE - 1) / WAVE};
     if (a.tile_box) HIP_TRY(h, launch_tile_bounds(a.pk_cur, h->N, const_cast<float4*>(a.tile_box), const_cast<float*>(a.tile_vmax), h->stream));
     HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
     for (int r = 0; r < reps; ++r) {
@@ -1031,6 +1038,22 @@ void* sfm_packed_state_ptr(SfmHandle* h, int* n_pad) {
 void* sfm_packed_z_ptr(SfmHandle* h) {
     if (!h || !h->z3) return nullptr;
     return h->zv[h->cur];
+}
+
+void* sfm_row_data_ptr(SfmHandle* h, int which, int* bytes_per_row) {
+    if (!h || which < 0 || which > 1) return nullptr;
+    if (bytes_per_row) *bytes_per_row = which == 0 ? (int)sizeof(float4) : (int)sizeof(uint32_t);
+    return which == 0 ? (void*)h->own : (void*)h->draws;
+}
+
+int sfm_resort(SfmHandle* h) {
+    int rc = bind(h);
+    if (rc) return rc;
+    if (!h->pk[0]) return fail(h, SFM_ERR_STATE, "sfm_upload_state has not been called");
+    if (!h->reordered || h->N == 0) return SFM_OK;
+    if (h->fsm_on && !(h->i_begin == 0 && h->i_end == h->N))
+        return fail(h, SFM_ERR_STATE, "sfm_resort on a shard with the device-side mode state machine");
+    return resort_rows(h);
 }
 
 const char* sfm_last_error(const SfmHandle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }

@@ -636,12 +636,6 @@ __global__ __launch_bounds__(BLOCK) void sfm_tick_kernel(const TickArgs a) {
 
         // 64 pairs x IPW rows: lane's record pj against the wave's rows
         auto step = [&](int j0, const float4 pj, float zj, float vzj, float rj) {
-            if (cut) {
-                const int u = j0 >> 6;                                    // uniform
-                const unsigned int w = (u >> 6) < 32 ? __builtin_amdgcn_readlane(keep_lo, u & 63)
-                                                     : __builtin_amdgcn_readlane(keep_hi, u & 63);
-                if (!((w >> ((u >> 6) & 31)) & 1u)) return;
-            }
             const bool clean = (j0 + WAVE <= N) && (ibase + IPW <= j0 || ibase >= j0 + WAVE);   // uniform
             if (clean) {
 #pragma unroll
@@ -667,7 +661,37 @@ __global__ __launch_bounds__(BLOCK) void sfm_tick_kernel(const TickArgs a) {
             }
         };
 
-        if (STAGED) {
+        if (cut) {
+            // Only the kept partner tiles are visited, in ascending order, each as one coalesced 1-KiB load per
+            // wave straight from L2 (the next kept tile's load is in flight while this one is evaluated).  TEAM 4:
+            // the waves take the kept tiles round-robin.
+            const int n_t = (N + WAVE - 1) / WAVE;
+            int ord = 0;                                               // uniform
+            bool have = false;
+            int c_j0 = 0;
+            float4 c_pk = make_float4(0.f, 0.f, 0.f, 0.f);
+            float2 c_zv = make_float2(0.f, 0.f);
+            float c_rad = 0.0f;
+            for (int t = 0; t * WAVE < n_t; ++t) {
+                const unsigned int kw = t < 32 ? keep_lo : keep_hi;
+                unsigned long long m = __ballot((kw >> (t & 31)) & 1u);
+                while (m) {
+                    const int b = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    if (TEAM > 1 && (ord++ & (TEAM - 1)) != wave) continue;
+                    const int j0 = (t * WAVE + b) * WAVE;            // rows up to N_pad are allocated
+                    const float4 n_pk = a.pk_cur[j0 + lane];
+                    float2 n_zv = make_float2(0.f, 0.f);
+                    float n_rad = 0.0f;
+                    if (Z3) n_zv = a.zv_cur[j0 + lane];
+                    if (RAD) n_rad = a.radius[j0 + lane];
+                    if (have) step(c_j0, c_pk, c_zv.x, c_zv.y, c_rad);
+                    c_j0 = j0; c_pk = n_pk; c_zv = n_zv; c_rad = n_rad;
+                    have = true;
+                }
+            }
+            if (have) step(c_j0, c_pk, c_zv.x, c_zv.y, c_rad);
+        } else if (STAGED) {
             const int ntiles = (N + TILE_J - 1) / TILE_J;
             float4 r_pk = a.pk_cur[tid];
             float2 r_zv = make_float2(0.f, 0.f);
@@ -890,25 +914,30 @@ __global__ __launch_bounds__(WAVE) void sfm_tile_bounds_kernel(const float4* __r
     if (lane == 0) { box[t] = make_float4(x0, y0, x1, y1); vmax[t] = v; }
 }
 
-// Compacts the tile-pair items the symmetric kernel has to evaluate: one candidate per thread, same (bx, shift)
-// enumeration as the kernel's 2-D grid.  Diagonal items are always kept.
-__global__ void sfm_pair_list_kernel(const float4* __restrict__ box, const float* __restrict__ vmax, int n_t, float lam,
-                                     float cut_scale, float cut_pad, uint32_t* __restrict__ work, int* __restrict__ count) {
-    const int bx = blockIdx.x * blockDim.x + threadIdx.x;
+// Compacts the tile-pair items the symmetric kernel has to evaluate: one candidate per thread, (bx, shift) with
+// bx an own tile and tb = bx + shift (mod n_t).  Own-own pairs are kept once (shift <= n_t / 2, as in the kernel's 2-D
+// grid); a pair with a tile of another rank is kept by both ranks, each evaluating its own side only (bit 31).
+// Diagonal items (shift 0) are always kept and carry two diagonal tiles each.
+constexpr uint32_t WORK_ONE_SIDED = 0x80000000u;
+__global__ void sfm_pair_list_kernel(const float4* __restrict__ box, const float* __restrict__ vmax, int n_t, int t_lo, int t_hi,
+                                     float lam, float cut_scale, float cut_pad, uint32_t* __restrict__ work,
+                                     int* __restrict__ count) {
+    const int bx = t_lo + blockIdx.x * blockDim.x + threadIdx.x;
     const int shift = blockIdx.y;
-    if (bx >= n_t) return;
+    if (bx >= t_hi) return;
     bool keep;
+    uint32_t one = 0u;
     if (shift == 0) {
-        keep = bx < ((n_t + 1) >> 1);
+        keep = (bx - t_lo) < ((t_hi - t_lo + 1) >> 1);
     } else {
-        keep = !(!(n_t & 1) && shift == (n_t >> 1) && bx >= (n_t >> 1));
-        if (keep) {
-            int tb = bx + shift;
-            if (tb >= n_t) tb -= n_t;
-            keep = !tiles_negligible(box[bx], vmax[bx], box[tb], vmax[tb], lam, cut_scale, cut_pad);
-        }
+        int tb = bx + shift;
+        if (tb >= n_t) tb -= n_t;
+        const bool own = tb >= t_lo && tb < t_hi;
+        if (own) keep = shift <= (n_t >> 1) && !(!(n_t & 1) && shift == (n_t >> 1) && bx >= (n_t >> 1));
+        else { keep = true; one = WORK_ONE_SIDED; }
+        if (keep) keep = !tiles_negligible(box[bx], vmax[bx], box[tb], vmax[tb], lam, cut_scale, cut_pad);
     }
-    if (keep) work[atomicAdd(count, 1)] = (uint32_t)bx | ((uint32_t)shift << 16);
+    if (keep) work[atomicAdd(count, 1)] = (uint32_t)bx | ((uint32_t)shift << 16) | one;
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -943,21 +972,25 @@ __global__ __launch_bounds__(BLOCK) void sfm_pair_sym_kernel(const float4* __res
     const int lane = tid & (WAVE - 1);
     const int wave = uniform(tid >> 6);
     const int n_t = sa.n_t;
-    const int half_up = (n_t + 1) >> 1;
+    const int half_up = (sa.t_hi - sa.t_lo + 1) >> 1;      // diagonal items pair own tile bx with bx + half_up
     unsigned long long t_start = 0;
     if (sa.stamps) t_start = __builtin_amdgcn_s_memrealtime();
     // work items: the (bx, shift) of the 2-D grid, or -- cutoff on -- entries of the compacted list, strided
     const int n_items = sa.work ? *sa.work_count : 1;
   for (int item = sa.work ? (int)blockIdx.x : 0; item < n_items; item += (sa.work ? (int)gridDim.x : 1)) {
     int shift = blockIdx.y, bx = blockIdx.x;      // shift = tile distance: 0 = diagonal items
-    if (sa.work) { const uint32_t w = sa.work[item]; bx = (int)(w & 0xffffu); shift = (int)(w >> 16); }
+    bool one_sided = false;                       // tb belongs to another rank: only tile ta's side is kept
+    if (sa.work) {
+        const uint32_t w = sa.work[item];
+        bx = (int)(w & 0xffffu); shift = (int)((w >> 16) & 0x7fffu); one_sided = (w & WORK_ONE_SIDED) != 0u;
+    }
     int ta, tb, sig0, nsteps;
     bool diag = false;
     if (shift == 0) {
         // diagonal tiles are half the work (32 steps): two of them share a workgroup, two waves each
-        if (bx >= half_up) return;                    // (never in the list)
+        if (bx - sa.t_lo >= half_up) return;          // (never in the list)
         ta = (wave < 2) ? bx : bx + half_up;
-        if (ta >= n_t) { ta = -1; }
+        if (ta >= sa.t_hi) { ta = -1; }
         tb = ta;
         diag = true;
         sig0 = 1 + 16 * (wave & 1);               // sigma 1..16 / 17..32 (sigma = 32 is one-sided)
@@ -1003,9 +1036,14 @@ __global__ __launch_bounds__(BLOCK) void sfm_pair_sym_kernel(const float4* __res
         // sigma = 32 on a diagonal tile meets every unordered pair {l, l+32} in BOTH lanes: one-sided there
         const bool tail_one_sided = diag && (sig0 + nsteps - 1 == 32);        // uniform
         if (nsteps == 16) {                      // the normal case: fixed trip count, steps interleaved 3-way
+            if (one_sided) {
+#pragma unroll 4
+                for (int s = 0; s < 16; ++s) step(false);
+            } else {
 #pragma unroll 3
-            for (int s = 0; s < 15; ++s) step(true);
-            if (tail_one_sided) step(false); else step(true);
+                for (int s = 0; s < 15; ++s) step(true);
+                if (tail_one_sided) step(false); else step(true);
+            }
         } else {                                 // timing probe (SymArgs::debug_steps)
             for (int s = 0; s < nsteps; ++s) step(true);
         }
@@ -1021,7 +1059,7 @@ __global__ __launch_bounds__(BLOCK) void sfm_pair_sym_kernel(const float4* __res
         if (tid < 2 * WAVE) {
             const int g = tid >> 6;                       // 0 or 1
             const int t = (g == 0) ? bx : bx + half_up;
-            if (t < n_t) {
+            if (t < sa.t_hi) {
                 const int p = tid & (WAVE - 1);
                 const float2 a0 = s_fi[2 * g][p], a1 = s_fi[2 * g + 1][p], b0 = s_fj[2 * g][p], b1 = s_fj[2 * g + 1][p];
                 sa.slab[(size_t)t * sa.stride + t * WAVE + p] = make_float2(((a0.x + a1.x) + b0.x) + b1.x,
@@ -1033,7 +1071,7 @@ __global__ __launch_bounds__(BLOCK) void sfm_pair_sym_kernel(const float4* __res
         if (tid < WAVE) {     // force on tile ta's pedestrians from tile tb
             const float2 a0 = s_fi[0][p], a1 = s_fi[1][p], a2 = s_fi[2][p], a3 = s_fi[3][p];
             sa.slab[(size_t)tb * sa.stride + ta * WAVE + p] = make_float2(((a0.x + a1.x) + a2.x) + a3.x, ((a0.y + a1.y) + a2.y) + a3.y);
-        } else {              // force on tile tb's pedestrians from tile ta
+        } else if (!one_sided) {   // force on tile tb's pedestrians from tile ta
             const float2 a0 = s_fj[0][p], a1 = s_fj[1][p], a2 = s_fj[2][p], a3 = s_fj[3][p];
             sa.slab[(size_t)ta * sa.stride + tb * WAVE + p] = make_float2(((a0.x + a1.x) + a2.x) + a3.x, ((a0.y + a1.y) + a2.y) + a3.y);
         }
@@ -1066,14 +1104,15 @@ __global__ __launch_bounds__(EPI_BLOCK) void sfm_sym_epilogue_kernel(const TickA
     const int tid = threadIdx.x;
     const int lane = tid & (WAVE - 1);
     const int wave = uniform(tid >> 6);
-    const int t = blockIdx.x;
+    const int t = sa.t_lo + blockIdx.x;
     const int N = a.N;
+    const int i_end = a.i_end;                             // rows of this handle end here (whole crowd: N)
     const int i = t * WAVE + lane;
 
     // own state first: independent of the slab, so its latency overlaps the column sum
     float4 st = make_float4(0.f, 0.f, 0.f, 0.f), o = st;
     uint32_t nd0 = 0;
-    if (wave == 0 && i < N) { st = a.pk_cur[i]; o = a.own[i]; if (a.flags & 2u) nd0 = a.draws[i]; }
+    if (wave == 0 && i < i_end) { st = a.pk_cur[i]; o = a.own[i]; if (a.flags & 2u) nd0 = a.draws[i]; }
 
     // 1. slab column sums
     float2 acc = make_float2(0.f, 0.f);
@@ -1126,7 +1165,7 @@ __global__ __launch_bounds__(EPI_BLOCK) void sfm_sym_epilogue_kernel(const TickA
     if (exact) {
         for (int p = wave; p < WAVE; p += EPI_WAVES) {
             const int ip = t * WAVE + p;
-            if (ip >= N) break;
+            if (ip >= i_end) break;
             const float4 si = a.pk_cur[ip];
             const float xi = uniform(si.x), yi = uniform(si.y), vxi = uniform(si.z), vyi = uniform(si.w);
             float gx = 0.f, gy = 0.f;
@@ -1147,7 +1186,7 @@ __global__ __launch_bounds__(EPI_BLOCK) void sfm_sym_epilogue_kernel(const TickA
     if (exact) __syncthreads();
     if (wave != 0) return;
     if (exact && lane == 0) sa.tile_flag[t] = 0;      // re-armed for the next tick
-    const bool live = i < N;                           // padding rows ride along (wave reductions below) but never store
+    const bool live = i < i_end;                           // padding rows ride along (wave reductions below) but never store
 
     // 4. lane-parallel epilogue for the 64 pedestrians of the tile
     float2 g = s_sum[0][lane];
@@ -1311,9 +1350,10 @@ hipError_t launch_sym_pair(const TickArgs& a, const SymArgs& sa, hipStream_t st)
         // cutoff on: compact the tile pairs that have to be evaluated, then a resident grid strides over them
         hipError_t e = hipMemsetAsync(const_cast<int*>(sa.work_count), 0, sizeof(int), st);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(sfm_pair_list_kernel, dim3((sa.n_t + 255) / 256, sa.n_t / 2 + 1), dim3(256), 0, st, a.tile_box,
-                           a.tile_vmax, sa.n_t, a.ped.lam, a.cut_scale, a.cut_pad, const_cast<uint32_t*>(sa.work),
-                           const_cast<int*>(sa.work_count));
+        const bool whole = sa.t_lo == 0 && sa.t_hi == sa.n_t;      // a shard also looks at partners behind it
+        hipLaunchKernelGGL(sfm_pair_list_kernel, dim3((sa.t_hi - sa.t_lo + 255) / 256, whole ? sa.n_t / 2 + 1 : sa.n_t), dim3(256), 0, st,
+                           a.tile_box, a.tile_vmax, sa.n_t, sa.t_lo, sa.t_hi, a.ped.lam, a.cut_scale, a.cut_pad,
+                           const_cast<uint32_t*>(sa.work), const_cast<int*>(sa.work_count));
         e = hipGetLastError();
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(sfm_pair_sym_kernel, dim3(256 * 8 * 2), dim3(BLOCK), 0, st, a.pk_cur, a.ped, sa);
@@ -1331,7 +1371,7 @@ hipError_t launch_tile_bounds(const float4* pk, int N, float4* box, float* vmax,
 
 hipError_t launch_sym_epilogue(const TickArgs& a, const SymArgs& sa, hipStream_t st) {
     if (a.N <= 0) return hipSuccess;
-    hipLaunchKernelGGL((sfm_sym_epilogue_kernel<false>), dim3(sa.n_t), dim3(EPI_BLOCK), 0, st, a, sa);
+    hipLaunchKernelGGL((sfm_sym_epilogue_kernel<false>), dim3(sa.t_hi - sa.t_lo), dim3(EPI_BLOCK), 0, st, a, sa);
     return hipGetLastError();
 }
 

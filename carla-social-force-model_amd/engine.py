@@ -309,6 +309,17 @@ class SfmEngine:
     def packed_z_ptr(self):
         return self._lib.sfm_packed_z_ptr(self._h)
 
+    def row_data_ptr(self, which):
+        """(device pointer, bytes per row) of a per-row array a sharded driver gathers before ``resort``:
+        0 = {waypoint x, waypoint y, target speed, radius}, 1 = waypoint draw counters."""
+        b = C.c_int(0)
+        p = self._lib.sfm_row_data_ptr(self._h, int(which), C.byref(b))
+        return p, b.value
+
+    def resort(self):
+        """Re-pack the rows spatially now (sfm_resort)."""
+        self._check(self._lib.sfm_resort(self._h), "sfm_resort")
+
     def timing(self):
         """(elapsed_ms, ticks, launches) of the last tick()/run(), HIP events on the handle's stream."""
         ms, t, l = C.c_float(0), C.c_int(0), C.c_int(0)

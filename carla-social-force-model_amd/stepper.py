@@ -10,6 +10,8 @@ the CPU ``gloo`` tests drive the same partition / collective logic with a host e
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 from .engine import SfmEngine
@@ -82,6 +84,21 @@ class HipShardEngine:
             out.append((self._view(zptr, 2), 2))
         return out
 
+    def row_data(self):
+        """[(flat fp32 tensor aliasing a per-row array only its owner keeps current, floats per row), ...]: what a
+        sharded driver all-gathers before ``resort`` (waypoints + target speed + radius; waypoint draw counters,
+        moved as raw 32-bit words)."""
+        out = []
+        for which in (0, 1):
+            ptr, nbytes = self.engine.row_data_ptr(which)
+            out.append((self._view(ptr, nbytes // 4), nbytes // 4))
+        return out
+
+    def resort(self):
+        self.engine.resort()
+
+    auto_resort = True          # a whole-crowd handle re-packs its rows by itself (SFM_RESORT_EVERY)
+
     def state(self):
         return self.engine.state()
 
@@ -95,30 +112,47 @@ class HipShardEngine:
 class ShardedStepper:
     """K ticks of the CARLA-free loop across ``world`` ranks."""
 
-    def __init__(self, engine, scenario, rank=0, world=1, group=None, redraw=True):
+    def __init__(self, engine, scenario, rank=0, world=1, group=None, redraw=True, resort_every=None):
         self.engine, self.rank, self.world, self.group, self.redraw = engine, rank, world, group, redraw
         self.n, self.n_pad = engine.load(scenario, redraw=redraw)
         self.lo, self.hi, self.chunk = shard_bounds(self.n, self.n_pad, rank, world)
         engine.set_shard(self.lo, self.hi)
         self.ticks_done = 0
+        # rows are kept spatially packed (compact 64-row tiles); pedestrians walk, so the packing is renewed every
+        # `resort_every` ticks.  One rank: the engine does it itself.  Shards: gather the owner-only per-row arrays,
+        # then every rank re-packs identically and carries on with rows [lo, hi) of the new order.
+        if resort_every is None:
+            resort_every = int(os.environ.get("SFM_RESORT_EVERY", "64"))
+        self.resort_every = resort_every
+        self.since_resort = 0
 
     def exchange(self, force=False):
         """The one collective of a tick: in-place all-gather of the packed records.  ``force`` issues it on a
         single-rank group too (used to exercise the RCCL path on a one-GPU box)."""
         if self.world == 1 and not force:
             return
+        self._gather(self.engine.packed())
+
+    def _gather(self, buffers):
         import torch.distributed as dist
-        for buf, width in self.engine.packed():
+        for buf, width in buffers:
             mine = buf[self.rank * self.chunk * width:(self.rank + 1) * self.chunk * width]
             dist.all_gather_into_tensor(buf, mine, group=self.group)
 
     def step(self, ticks=1):
-        if self.world == 1:
+        driver_resorts = self.resort_every > 0 and not (self.world == 1 and getattr(self.engine, "auto_resort", False))
+        if self.world == 1 and not driver_resorts:
             self.engine.run(ticks, redraw=self.redraw)      # no exchange needed: launch back to back
         else:
             for _ in range(ticks):
+                if driver_resorts and self.since_resort >= self.resort_every:
+                    if self.world > 1:
+                        self._gather(self.engine.row_data())
+                    self.engine.resort()
+                    self.since_resort = 0
                 self.engine.run(1, redraw=self.redraw)
                 self.exchange()
+                self.since_resort += 1
         self.ticks_done += ticks
 
     def local_rows(self):

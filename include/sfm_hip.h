@@ -189,6 +189,15 @@ int sfm_download_draw_counts(SfmHandle* h, uint32_t* counts);
 void* sfm_packed_state_ptr(SfmHandle* h, int* n_pad);
 /* Same for the {z, vz} records (2 floats) of the 3-D variant; NULL when the crowd is planar. */
 void* sfm_packed_z_ptr(SfmHandle* h);
+/* Rows are kept in an internal spatial order (compact 64-row tiles); a device-resident whole-crowd run re-packs them
+ * every SFM_RESORT_EVERY ticks by itself.  A sharded run cannot: a rank only keeps its own rows' waypoints and draw
+ * counters current.  Its driver therefore, every few dozen ticks, all-gathers the two per-row arrays below (row-indexed
+ * like the packed state, N_pad rows; which = 0: {waypoint x, waypoint y, target speed, radius}, 16 bytes per row;
+ * which = 1: waypoint draw counter, 4 bytes per row) and then calls sfm_resort on every rank: the same state gives the
+ * same order everywhere, and rank r goes on with rows [lo, hi) of the new order.  No-op when the order is off (N < 2048).
+ * SFM_ERR_STATE on a shard whose mode state machine lives on the device (that state is keyed by pedestrian, not gathered). */
+void* sfm_row_data_ptr(SfmHandle* h, int which, int* bytes_per_row);
+int sfm_resort(SfmHandle* h);
 
 /* ---- diagnostics ----------------------------------------------------------------------------------- */
 

@@ -78,3 +78,73 @@ def test_row_shards_reassemble_the_full_tick():
             assert np.isnan(lo[k][512:]).all() and np.isnan(hi[k][:512]).all()     # rows outside the shard untouched
     finally:
         os.environ.pop("SFM_SYM", None)
+
+
+@pytest.mark.parametrize("path", ["ordered", "symmetric"])
+def test_two_shards_with_row_repacking_match_the_whole_crowd_run(path, monkeypatch):
+    """What two ranks do, replayed on one GPU with two handles: a tick on the own rows, the exchange of the packed
+    records (here a device copy instead of the all-gather), and every 4 ticks the re-pack protocol of
+    sfm_resort -- exchange the owner-only per-row arrays, re-pack identically on both handles, carry on with the same
+    row ranges (now other pedestrians).  Must equal the whole-crowd handle, which re-packs by itself, bit for bit."""
+    import torch
+    from carla_social_force_model_amd.stepper import HipShardEngine, shard_bounds
+    # ordered kernel on every handle: bit-identical.  Symmetric kernel (tile-aligned shards + tile-pair list): a pair
+    # across the shard boundary is evaluated one-sided by both handles, so sums are ordered differently -> rounding only.
+    env = {"SFM_CUTOFF": "1", "SFM_RESORT_EVERY": "4"}
+    env.update({"SFM_SYM": "0", "SFM_IPW": "4", "SFM_TEAM": "1"} if path == "ordered" else {"SFM_SYM": "1"})
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    cfg = default_sfm_config(("acceleration_force", "pedestrian_force", "border_force", "static_obstacle_force"))
+    sc = scenarios.make_scenario(3000, 97, n_borders=20, n_static=10, border_len=(5.0, 25.0))
+    ticks = 11
+    whole = HipShardEngine(cfg, 0.05)
+    whole.load(sc)
+    whole.run(ticks)
+    ref = whole.engine.state()
+    whole_variant = whole.engine.kernel_variant()
+    whole.close()
+
+    assert ("sym" in whole_variant) == (path == "symmetric")
+    ranks = [HipShardEngine(cfg, 0.05) for _ in range(2)]
+    bounds = []
+    for r, e in enumerate(ranks):
+        n, n_pad = e.load(sc)
+        lo, hi, chunk = shard_bounds(n, n_pad, r, 2)
+        e.set_shard(lo, hi)
+        bounds.append((lo, hi, chunk))
+
+    def exchange(buffers_of):
+        """every handle receives the other handle's own chunk of each buffer"""
+        bufs = [buffers_of(e) for e in ranks]
+        for r in range(2):
+            chunk = bounds[r][2]
+            for (src, width), (dst, _) in zip(bufs[r], bufs[1 - r]):
+                dst[r * chunk * width:(r + 1) * chunk * width].copy_(src[r * chunk * width:(r + 1) * chunk * width])
+        torch.cuda.synchronize()
+
+    moved = 0
+    for t in range(ticks):
+        if t and t % 4 == 0:
+            exchange(lambda e: e.row_data())
+            before = ranks[0].engine.state()[0]
+            for e in ranks:
+                e.resort()
+            after = ranks[0].engine.state()[0]
+            moved += int((np.isnan(before[:, 0]) != np.isnan(after[:, 0])).sum())   # pedestrians that changed rank
+        for e in ranks:
+            e.run(1)
+            e.synchronize()
+        exchange(lambda e: e.packed())
+    assert moved > 0
+    got = [e.engine.state() for e in ranks]
+    for k in range(3):
+        mine0, mine1 = ~np.isnan(got[0][k][:, 0]), ~np.isnan(got[1][k][:, 0])
+        assert (mine0 ^ mine1).all()                       # every pedestrian is owned by exactly one handle
+        merged = np.where(mine0[:, None], got[0][k], got[1][k])
+        if path == "ordered":
+            assert np.array_equal(merged, ref[k])
+        else:
+            assert np.allclose(merged, ref[k], rtol=2e-5, atol=2e-5)
+    assert all(("sym" in e.engine.kernel_variant()) == (path == "symmetric") for e in ranks)
+    for e in ranks:
+        e.close()

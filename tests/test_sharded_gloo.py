@@ -19,7 +19,12 @@ from oracle import sfm_oracle as O
 
 class OracleShardEngine:
     """Same interface as stepper.HipShardEngine, computing on the host in float64 and keeping the packed
-    {x,y,vx,vy} records in a CPU fp32 tensor (what the device buffer holds)."""
+    {x,y,vx,vy} records in a CPU fp32 tensor (what the device buffer holds).  Like the device engine it keeps its
+    rows in an internal order (``ids``: row -> caller's index), only keeps the waypoints / draw counters of its own
+    rows current, and re-packs the rows on ``resort`` -- here simply by x, which is enough to move pedestrians
+    between ranks."""
+
+    auto_resort = False
 
     def __init__(self, cfg, dt):
         self.prm = O.OracleParams.from_config(cfg)
@@ -33,8 +38,11 @@ class OracleShardEngine:
         v = self.buf.view(self.n_pad, 4).numpy()
         v[:sc.n, 0:2] = sc.loc[:, :2]
         v[:sc.n, 2:4] = sc.vel[:, :2]
-        self.wp = sc.waypoint.copy()
-        self.draws = np.zeros(sc.n, dtype=np.int64)
+        self.own = torch.zeros(self.n_pad * 4, dtype=torch.float64)          # {wx, wy, target speed, radius} per row
+        o = self.own.view(self.n_pad, 4).numpy()
+        o[:sc.n, 0:2] = sc.waypoint[:, :2]; o[:sc.n, 2] = sc.target_speed; o[:sc.n, 3] = sc.radius
+        self.draws = torch.zeros(self.n_pad, dtype=torch.int64)
+        self.ids = np.arange(sc.n)
         self.geom = O.Geometry(sc.borders, sc.border_centers, sc.border_lengths, sc.static_obstacles,
                                sc.dynamic_obstacles, sc.dynamic_vel)
         return self.n, self.n_pad
@@ -43,34 +51,52 @@ class OracleShardEngine:
         self.lo, self.hi = lo, hi
 
     def run(self, ticks, redraw=True):
-        sc, lo, hi = self.sc, self.lo, self.hi
+        sc, lo, hi, n = self.sc, self.lo, self.hi, self.n
         for _ in range(ticks):
             v = self.buf.view(self.n_pad, 4).numpy()
-            loc = np.zeros((self.n, 3)); vel = np.zeros((self.n, 3))
-            loc[:, :2] = v[:self.n, 0:2]; vel[:, :2] = v[:self.n, 2:4]
-            _, _, v_new, _, _ = c_oracle.tick(loc, vel, self.wp, sc.target_speed, sc.radius, np.zeros(self.n, bool),
+            o = self.own.view(self.n_pad, 4).numpy()
+            d = self.draws.numpy()
+            loc = np.zeros((n, 3)); vel = np.zeros((n, 3)); wp = np.zeros((n, 3))
+            loc[:, :2] = v[:n, 0:2]; vel[:, :2] = v[:n, 2:4]; wp[:, :2] = o[:n, 0:2]
+            _, _, v_new, _, _ = c_oracle.tick(loc, vel, wp, o[:n, 2].copy(), o[:n, 3].copy(), np.zeros(n, bool),
                                               self.geom, self.prm, self.dt, rows=(lo, hi), nthreads=1)
             if redraw:
-                hit = np.nonzero(O.arrived(loc[lo:hi], self.wp[lo:hi], 2.0))[0] + lo
-                self.draws[hit] += 1
-                self.wp[hit, :2] = O.redraw_waypoint(hit, self.draws[hit], sc.seed, sc.world_side)
+                hit = np.nonzero(O.arrived(loc[lo:hi], wp[lo:hi], 2.0))[0] + lo
+                d[hit] += 1
+                o[hit, 0:2] = O.redraw_waypoint(self.ids[hit], d[hit], sc.seed, sc.world_side)   # keyed by the caller's index
             v[lo:hi, 0:2] = (loc[lo:hi] + self.dt * v_new)[:, :2]
             v[lo:hi, 2:4] = v_new[:, :2]
 
     def packed(self):
         return [(self.buf, 4)]
 
+    def row_data(self):
+        return [(self.own, 4), (self.draws, 1)]
+
+    def resort(self):
+        n = self.n
+        v = self.buf.view(self.n_pad, 4).numpy()
+        order = np.argsort(v[:n, 0], kind="stable")
+        v[:n] = v[:n][order]
+        o = self.own.view(self.n_pad, 4).numpy()
+        o[:n] = o[:n][order]
+        d = self.draws.numpy()
+        d[:n] = d[:n][order]
+        self.ids = self.ids[order]
+
     def state(self):
         v = self.buf.view(self.n_pad, 4).numpy()
+        o = self.own.view(self.n_pad, 4).numpy()
         loc = np.full((self.n, 3), np.nan); vel = np.full((self.n, 3), np.nan); wp = np.full((self.n, 2), np.nan)
         lo, hi = self.lo, self.hi                     # like the HIP engine: only this rank's pedestrians
-        loc[lo:hi, :2] = v[lo:hi, 0:2]; vel[lo:hi, :2] = v[lo:hi, 2:4]; loc[lo:hi, 2] = 0.0; vel[lo:hi, 2] = 0.0
-        wp[lo:hi] = self.wp[lo:hi, :2]
+        who = self.ids[lo:hi]
+        loc[who, :2] = v[lo:hi, 0:2]; vel[who, :2] = v[lo:hi, 2:4]; loc[who, 2] = 0.0; vel[who, 2] = 0.0
+        wp[who] = o[lo:hi, 0:2]
         return loc, vel, wp
 
 
 CFG = default_sfm_config(("acceleration_force", "pedestrian_force", "border_force"))
-N, TICKS = 700, 6
+N, TICKS, RESORT_EVERY = 700, 7, 3      # two re-packs inside the run: rows change rank twice
 
 
 def _scenario():
@@ -82,7 +108,7 @@ def _worker(rank, world, port, out):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        st = ShardedStepper(OracleShardEngine(CFG, 0.05), _scenario(), rank=rank, world=world)
+        st = ShardedStepper(OracleShardEngine(CFG, 0.05), _scenario(), rank=rank, world=world, resort_every=RESORT_EVERY)
         st.step(TICKS)
         loc, vel, wp = st.gather_state()
         if rank == 0:
@@ -99,7 +125,7 @@ def _free_port():
 
 @pytest.mark.parametrize("world", [2, 4])
 def test_sharded_equals_single_rank(world, tmp_path):
-    single = ShardedStepper(OracleShardEngine(CFG, 0.05), _scenario())
+    single = ShardedStepper(OracleShardEngine(CFG, 0.05), _scenario(), resort_every=RESORT_EVERY)
     single.step(TICKS)
     loc1, vel1, wp1 = single.gather_state()
     out = str(tmp_path / "sharded.npz")
