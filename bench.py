@@ -11,9 +11,10 @@ Metric: SFM ticks/s (BASELINE.json "SFM ticks/s and ns/pedestrian-pair"); ns/pai
 Workloads (--workload overrides the default):
   G = 1  -> c2: N = 4 096, pedestrian_force + acceleration_force        (the config the metric is quoted on)
   G > 1  -> c5: N = 262 144 + 2 000 borders + 256 static + 512 dynamic obstacles, all forces, STRONG scaling:
-            pedestrians sharded by index, one RCCL all-gather of the packed state per tick.  Rank 0 also times
-            a few ticks of the SAME workload on one GPU before the run ("single_gpu_same_workload") so the
-            strong-scaling speed-up can be read off one line.
+            pedestrians sharded by row (whole 64-row tiles of a spatial packing), one RCCL all-gather of the packed
+            state per tick, plus a gather of the waypoint arrays and an identical re-pack on every rank each 64 ticks.
+            Rank 0 also times 40 ticks of the SAME workload on one GPU before the run ("single_gpu_same_workload")
+            so the strong-scaling speed-up can be read off one line.
 """
 import argparse
 import json
@@ -139,12 +140,12 @@ def main():
         # the same workload on ONE GPU, a few ticks, so the strong-scaling speed-up is on this line
         e1 = HipShardEngine(cfg, dt, device=local)
         s1 = ShardedStepper(e1, sc)
-        s1.step(1)
+        s1.step(10)
         e1.synchronize()
         t0 = time.perf_counter()
-        s1.step(3)
+        s1.step(40)
         e1.synchronize()
-        single_ref = 3.0 / (time.perf_counter() - t0)
+        single_ref = 40.0 / (time.perf_counter() - t0)
         e1.close()
 
     eng = HipShardEngine(cfg, dt, device=local)
@@ -156,6 +157,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    st.exchange()                 # brings the communicator up outside the timed region (idempotent on a fresh state)
     st.step(args.warmup)
     barrier()
     t0 = time.perf_counter()

@@ -19,6 +19,8 @@ hipError_t launch_tick(int ipw, int team, bool z3, bool rad, const TickArgs& a, 
 hipError_t launch_arrived(const float4* pk, const float4* own, int N, float thr2, uint8_t* mask, hipStream_t st);
 hipError_t launch_sym_pair(const TickArgs& a, const SymArgs& sa, hipStream_t st);
 hipError_t launch_sym_epilogue(const TickArgs& a, const SymArgs& sa, hipStream_t st);
+hipError_t launch_strip_bounds(const float4* box, const float* vmax, int n_t, int tps, int n_strips, float4* sbox, float* svmax,
+                               hipStream_t st);
 hipError_t launch_geometry(bool rad, const TickArgs& a, hipStream_t st);
 hipError_t launch_modes(const TickArgs& a, hipStream_t st);
 struct ReorderBufs { unsigned long long *key64_in, *key64_out; uint32_t *row_a, *row_b, *key32_in, *key32_out; void* temp; size_t temp_bytes; };
@@ -83,6 +85,8 @@ struct SfmHandle {
     // tile-granular cutoff of provably negligible pedestrian pairs
     float4* tile_box = nullptr;            // [2][n_t]: the lite cutoff ping-pongs (epilogue k writes the boxes of tick k+1)
     float* tile_vmax = nullptr;
+    float4* strip_box = nullptr;           // [n_t]: boxes / speeds of runs of tiles (two-level list building, n_t >= 1024)
+    float* strip_vmax = nullptr;
     int box_cur = 0;
     bool boxes_valid = false;
     uint32_t* work = nullptr;
@@ -279,6 +283,8 @@ int sfm_destroy(SfmHandle* h) {
     if (h->ids) hipFree(h->ids);
     if (h->tile_box) hipFree(h->tile_box);
     if (h->tile_vmax) hipFree(h->tile_vmax);
+    if (h->strip_box) hipFree(h->strip_box);
+    if (h->strip_vmax) hipFree(h->strip_vmax);
     if (h->work) hipFree(h->work);
     if (h->work_count) hipFree(h->work_count);
     free_geo(h->borders); free_geo(h->statics); free_geo(h->dynamics);
@@ -427,6 +433,11 @@ int sfm_download_dynamic_obstacles(SfmHandle* h, float* cx, float* cy, float* px
     return SFM_OK;
 }
 
+// Row length of the slab in float2: one tile more than the n_t * 64 columns, so that the same column of consecutive rows
+// (what an epilogue workgroup sums, what a run of list items writes) does not sit at a power-of-two stride -- those all
+// land on one HBM channel.
+static inline int slab_stride(int n_t) { return n_t * WAVE + WAVE; }
+
 int sfm_upload_state(SfmHandle* h, int N, const float* x, const float* y, const float* z, const float* vx,
                      const float* vy, const float* vz, const float* wx, const float* wy,
                      const float* target_speed, const float* radius, const uint8_t* crossing_mask) {
@@ -528,7 +539,7 @@ int sfm_upload_state(SfmHandle* h, int N, const float* x, const float* y, const 
     h->perm_stale = false;
     // slab of the symmetric path: n_t x (n_t*64) float2 (8.6 GB at N = 262 144), up to 16 GiB of the 288 GB
     h->n_t = (N + WAVE - 1) / WAVE;
-    const size_t need = (size_t)h->n_t * (size_t)h->n_t * WAVE;
+    const size_t need = (size_t)h->n_t * (size_t)slab_stride(h->n_t);
     if (!z3 && !rad && h->dpp_dir != 0 && h->sym_mode != 0 && need * sizeof(float2) <= ((size_t)16 << 30)) {
         if (need > h->slab_cap) { HIP_TRY(h, dev_realloc(h->slab, need)); h->slab_cap = need; }
         if (h->n_t > h->tile_cap) { HIP_TRY(h, dev_realloc(h->tile_flag, (size_t)h->n_t)); h->tile_cap = h->n_t; }
@@ -539,6 +550,8 @@ int sfm_upload_state(SfmHandle* h, int N, const float* x, const float* y, const 
     if (rad) for (int i = 0; i < N; ++i) h->r_max = std::fmax(h->r_max, radius[i]);
     HIP_TRY(h, dev_realloc(h->tile_box, (size_t)h->n_t * 2));
     HIP_TRY(h, dev_realloc(h->tile_vmax, (size_t)h->n_t * 2));
+    HIP_TRY(h, dev_realloc(h->strip_box, (size_t)h->n_t));
+    HIP_TRY(h, dev_realloc(h->strip_vmax, (size_t)h->n_t));
     h->box_cur = 0;
     h->boxes_valid = false;
     {
@@ -723,6 +736,14 @@ static int sync_perm(SfmHandle* h) {
     return SFM_OK;
 }
 
+// two-level tile-pair list: runs of tps tiles = the x-strips of the spatial packing; worth a launch from ~1000 tiles on
+static void strip_shape(const SfmHandle* h, int* tps, int* n_strips) {
+    *tps = std::max(1, h->strip_rows / WAVE);
+    bool on = h->reordered && h->n_t >= 1024 && *tps >= 8;
+    if (const char* ov = getenv("SFM_STRIPS")) on = atoi(ov) != 0;      // tests force either way
+    *n_strips = on ? (h->n_t + *tps - 1) / *tps : 0;
+}
+
 static int run_ticks(SfmHandle* h, int ticks, uint32_t flags) {
     int rc = bind(h);
     if (rc) return rc;
@@ -734,8 +755,10 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags) {
     int ipw = 1, team = 1;
     pick_shape(h, n_local, &ipw, &team);
     h->ipw_last = ipw;
+    int tps = 1, n_strips = 0;
+    strip_shape(h, &tps, &n_strips);
     // symmetric path: whole crowd on this handle, planar, no radius; auto mode wants >= 4 tiles
-    const size_t need = (size_t)h->n_t * (size_t)h->n_t * WAVE;
+    const size_t need = (size_t)h->n_t * (size_t)slab_stride(h->n_t);
     bool order_pays, list_cut;                      // compact tiles only matter to the tile cutoff and the geometry kernel
     {
         TickArgs probe;
@@ -791,10 +814,14 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags) {
             ++launches;
         }
         if (sym) {
-            SymArgs sa{h->slab, h->tile_flag, h->n_t, h->n_t * WAVE, h->dpp_dir, getenv("SFM_DEBUG_STEPS") ? atoi(getenv("SFM_DEBUG_STEPS")) : -1,
+            SymArgs sa{h->slab, h->tile_flag, h->n_t, slab_stride(h->n_t), h->dpp_dir, getenv("SFM_DEBUG_STEPS") ? atoi(getenv("SFM_DEBUG_STEPS")) : -1,
                        (a.tile_box && !lite) ? h->work : nullptr, (a.tile_box && !lite) ? h->work_count : nullptr,
                        lite ? a.tile_box : nullptr, lite ? a.tile_vmax : nullptr, a.cut_scale, a.cut_pad, h->stamps,
-                       h->i_begin / WAVE, (h->i_end + WAVE - 1) / WAVE};
+                       h->strip_box, h->strip_vmax, tps, n_strips, h->i_begin / WAVE, (h->i_end + WAVE - 1) / WAVE};
+            if (sa.work && n_strips > 0) {
+                HIP_TRY(h, launch_strip_bounds(a.tile_box, a.tile_vmax, h->n_t, tps, n_strips, h->strip_box, h->strip_vmax, h->stream));
+                ++launches;
+            }
             if (sa.work) launches += 1;
             HIP_TRY(h, launch_sym_pair(a, sa, h->stream));
             if (fork) HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
@@ -835,14 +862,18 @@ int sfm_profile_dominant_kernel(SfmHandle* h, int reps, float* avg_us) {
     const int n_local = h->i_end - h->i_begin;
     int ipw = 1, team = 1;
     pick_shape(h, n_local, &ipw, &team);
+    int tps = 1, n_strips = 0;
+    strip_shape(h, &tps, &n_strips);
     TickArgs a;
     fill_args(h, a, 0);
     if (h->used_sym) a.geo = nullptr;
     const bool lite = a.tile_box_out != nullptr;
-    SymArgs sa{h->slab, h->tile_flag, h->n_t, h->n_t * WAVE, h->dpp_dir, -1, (a.tile_box && !lite) ? h->work : nullptr,
+    SymArgs sa{h->slab, h->tile_flag, h->n_t, slab_stride(h->n_t), h->dpp_dir, -1, (a.tile_box && !lite) ? h->work : nullptr,
                (a.tile_box && !lite) ? h->work_count : nullptr, lite ? a.tile_box : nullptr, lite ? a.tile_vmax : nullptr,
-               a.cut_scale, a.cut_pad, nullptr, h->i_begin / WAVE, (h->i_end + WAVE - 1) / WAVE};
+               a.cut_scale, a.cut_pad, nullptr, h->strip_box, h->strip_vmax, tps, n_strips, h->i_begin / WAVE, (h->i_end + WAVE - 1) / WAVE};
     if (a.tile_box) HIP_TRY(h, launch_tile_bounds(a.pk_cur, h->N, const_cast<float4*>(a.tile_box), const_cast<float*>(a.tile_vmax), h->stream));
+    if (sa.work && n_strips > 0)
+        HIP_TRY(h, launch_strip_bounds(a.tile_box, a.tile_vmax, h->n_t, tps, n_strips, h->strip_box, h->strip_vmax, h->stream));
     HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
     for (int r = 0; r < reps; ++r) {
         if (h->used_sym) HIP_TRY(h, launch_sym_pair(a, sa, h->stream));

@@ -105,6 +105,11 @@ struct SymArgs {
     const float* vmax;
     float cut_scale, cut_pad;
     unsigned long long* stamps;   // diagnostic builds of a run only (SFM_STAMPS): per workgroup {start, end} of s_memrealtime + HW id
+    // two-level list building (large crowds): boxes / largest speeds of runs of `tps` consecutive tiles (= the x-strips of
+    // the spatial packing); n_strips = 0: flat
+    const float4* sbox;
+    const float* svmax;
+    int tps, n_strips;
     int t_lo, t_hi;      // tiles of this handle's rows (a shard; whole crowd: 0, n_t).  Pairs with a tile outside are
                          // evaluated one-sided: the other side belongs to another rank, which evaluates it itself
 };

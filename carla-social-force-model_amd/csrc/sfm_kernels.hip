@@ -914,6 +914,31 @@ __global__ __launch_bounds__(WAVE) void sfm_tile_bounds_kernel(const float4* __r
     if (lane == 0) { box[t] = make_float4(x0, y0, x1, y1); vmax[t] = v; }
 }
 
+// Box and largest speed of each run of `tps` consecutive tiles (one wave per run).  A run is an x-strip of the spatial
+// packing, so its box is a slab of the map; any order is fine for correctness (the box is just the union).
+__global__ __launch_bounds__(WAVE) void sfm_strip_bounds_kernel(const float4* __restrict__ box, const float* __restrict__ vmax,
+                                                                int n_t, int tps, float4* __restrict__ sbox,
+                                                                float* __restrict__ svmax) {
+    const int s = blockIdx.x, lane = threadIdx.x;
+    const float inf = __builtin_inff();
+    float x0 = inf, y0 = inf, x1 = -inf, y1 = -inf, v = 0.0f;
+    for (int q = lane; q < tps; q += WAVE) {
+        const int t = s * tps + q;
+        if (t < n_t) {
+            const float4 b = box[t];
+            x0 = fminf(x0, b.x); y0 = fminf(y0, b.y); x1 = fmaxf(x1, b.z); y1 = fmaxf(y1, b.w);
+            v = fmaxf(v, vmax[t]);
+        }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        x0 = fminf(x0, __shfl_xor(x0, m)); y0 = fminf(y0, __shfl_xor(y0, m));
+        x1 = fmaxf(x1, __shfl_xor(x1, m)); y1 = fmaxf(y1, __shfl_xor(y1, m));
+        v = fmaxf(v, __shfl_xor(v, m));
+    }
+    if (lane == 0) { sbox[s] = make_float4(x0, y0, x1, y1); svmax[s] = v; }
+}
+
 // Compacts the tile-pair items the symmetric kernel has to evaluate: one candidate per thread, (bx, shift) with
 // bx an own tile and tb = bx + shift (mod n_t).  Own-own pairs are kept once (shift <= n_t / 2, as in the kernel's 2-D
 // grid); a pair with a tile of another rank is kept by both ranks, each evaluating its own side only (bit 31).
@@ -938,6 +963,68 @@ __global__ void sfm_pair_list_kernel(const float4* __restrict__ box, const float
         if (keep) keep = !tiles_negligible(box[bx], vmax[bx], box[tb], vmax[tb], lam, cut_scale, cut_pad);
     }
     if (keep) work[atomicAdd(count, 1)] = (uint32_t)bx | ((uint32_t)shift << 16) | one;
+}
+
+// The same list for large crowds, two levels: one wave per own tile tests the strips first, 64 at a time (a strip's box
+// contains its tiles' boxes and its speed bounds theirs, and tiles_negligible is monotone in both, so a negligible strip
+// holds only negligible tiles -- the result is exactly the flat kernel's), then the tiles of the surviving strips.
+__global__ __launch_bounds__(BLOCK) void sfm_pair_list2_kernel(const float4* __restrict__ box, const float* __restrict__ vmax,
+                                                               const SymArgs sa, float lam, uint32_t* __restrict__ work,
+                                                               int* __restrict__ count) {
+    constexpr int BUF = 256;                              // a wave collects its items in LDS: one atomic per flush
+    __shared__ uint32_t s_item[WAVES_PER_BLOCK][BUF];
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wave = uniform((int)(threadIdx.x >> 6));
+    const int bx = sa.t_lo + blockIdx.x * WAVES_PER_BLOCK + wave;
+    if (bx >= sa.t_hi) return;
+    uint32_t* buf = s_item[wave];
+    int n_buf = 0;                                         // uniform
+    auto flush = [&]() {
+        if (n_buf == 0) return;
+        int base = 0;
+        if (lane == 0) base = atomicAdd(count, n_buf);
+        base = __builtin_amdgcn_readfirstlane(base);
+        for (int q = lane; q < n_buf; q += WAVE) work[base + q] = buf[q];
+        n_buf = 0;
+    };
+    const int n_t = sa.n_t;
+    const float4 bt = box[bx];
+    const float vt = vmax[bx];
+    for (int sb = 0; sb < sa.n_strips; sb += WAVE) {
+        const int s = sb + lane;
+        const bool hit = s < sa.n_strips && !tiles_negligible(bt, vt, sa.sbox[min(s, sa.n_strips - 1)], sa.svmax[min(s, sa.n_strips - 1)],
+                                                              lam, sa.cut_scale, sa.cut_pad);
+        unsigned long long ms = __ballot(hit);
+        while (ms) {
+            const int s0 = (sb + __ffsll((long long)ms) - 1) * sa.tps;      // first tile of a surviving strip
+            ms &= ms - 1;
+            for (int q0 = 0; q0 < sa.tps; q0 += WAVE) {
+                const int tb = s0 + q0 + lane;
+                bool keep = (q0 + lane) < sa.tps && tb < n_t;
+                uint32_t item = 0u;
+                if (keep) {
+                    int shift = tb - bx;
+                    if (shift < 0) shift += n_t;
+                    if (shift == 0) {
+                        keep = (bx - sa.t_lo) < ((sa.t_hi - sa.t_lo + 1) >> 1);
+                    } else {
+                        const bool own = tb >= sa.t_lo && tb < sa.t_hi;
+                        if (own) keep = shift <= (n_t >> 1) && !(!(n_t & 1) && shift == (n_t >> 1) && bx >= (n_t >> 1));
+                        if (keep) keep = !tiles_negligible(bt, vt, box[tb], vmax[tb], lam, sa.cut_scale, sa.cut_pad);
+                        item = own ? 0u : WORK_ONE_SIDED;
+                    }
+                    item |= (uint32_t)bx | ((uint32_t)shift << 16);
+                }
+                const unsigned long long mk = __ballot(keep);
+                if (mk) {
+                    if (n_buf + WAVE > BUF) flush();
+                    if (keep) buf[n_buf + __popcll(mk & ((1ull << lane) - 1ull))] = item;
+                    n_buf += __popcll(mk);
+                }
+            }
+        }
+    }
+    flush();
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -977,7 +1064,11 @@ __global__ __launch_bounds__(BLOCK) void sfm_pair_sym_kernel(const float4* __res
     if (sa.stamps) t_start = __builtin_amdgcn_s_memrealtime();
     // work items: the (bx, shift) of the 2-D grid, or -- cutoff on -- entries of the compacted list, strided
     const int n_items = sa.work ? *sa.work_count : 1;
-  for (int item = sa.work ? (int)blockIdx.x : 0; item < n_items; item += (sa.work ? (int)gridDim.x : 1)) {
+    // list mode: a workgroup takes a contiguous run of the list (consecutive items share a tile: its rows stay hot in this
+    // CU's cache and no two workgroups hammer the same lines at the same moment)
+    const int run = sa.work ? (n_items + (int)gridDim.x - 1) / (int)gridDim.x : 1;
+    const int item0 = sa.work ? (int)blockIdx.x * run : 0;
+  for (int item = item0; item < min(n_items, item0 + run); ++item) {
     int shift = blockIdx.y, bx = blockIdx.x;      // shift = tile distance: 0 = diagonal items
     bool one_sided = false;                       // tb belongs to another rank: only tile ta's side is kept
     if (sa.work) {
@@ -1351,6 +1442,10 @@ hipError_t launch_sym_pair(const TickArgs& a, const SymArgs& sa, hipStream_t st)
         hipError_t e = hipMemsetAsync(const_cast<int*>(sa.work_count), 0, sizeof(int), st);
         if (e != hipSuccess) return e;
         const bool whole = sa.t_lo == 0 && sa.t_hi == sa.n_t;      // a shard also looks at partners behind it
+        if (sa.n_strips > 0)
+            hipLaunchKernelGGL(sfm_pair_list2_kernel, dim3((sa.t_hi - sa.t_lo + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), dim3(BLOCK), 0, st,
+                               a.tile_box, a.tile_vmax, sa, a.ped.lam, const_cast<uint32_t*>(sa.work), const_cast<int*>(sa.work_count));
+        else
         hipLaunchKernelGGL(sfm_pair_list_kernel, dim3((sa.t_hi - sa.t_lo + 255) / 256, whole ? sa.n_t / 2 + 1 : sa.n_t), dim3(256), 0, st,
                            a.tile_box, a.tile_vmax, sa.n_t, sa.t_lo, sa.t_hi, a.ped.lam, a.cut_scale, a.cut_pad,
                            const_cast<uint32_t*>(sa.work), const_cast<int*>(sa.work_count));
@@ -1366,6 +1461,13 @@ hipError_t launch_sym_pair(const TickArgs& a, const SymArgs& sa, hipStream_t st)
 hipError_t launch_tile_bounds(const float4* pk, int N, float4* box, float* vmax, hipStream_t st) {
     if (N <= 0) return hipSuccess;
     hipLaunchKernelGGL(sfm_tile_bounds_kernel, dim3((N + WAVE - 1) / WAVE), dim3(WAVE), 0, st, pk, N, box, vmax);
+    return hipGetLastError();
+}
+
+hipError_t launch_strip_bounds(const float4* box, const float* vmax, int n_t, int tps, int n_strips, float4* sbox, float* svmax,
+                               hipStream_t st) {
+    if (n_strips <= 0) return hipSuccess;
+    hipLaunchKernelGGL(sfm_strip_bounds_kernel, dim3(n_strips), dim3(WAVE), 0, st, box, vmax, n_t, tps, sbox, svmax);
     return hipGetLastError();
 }
 

@@ -394,8 +394,35 @@ def test_tile_cutoff_keeps_parity(order, sym, monkeypatch):
             assert times["grid"] < 0.8 * times["scrambled"], times
 
 
+def test_two_level_pair_list_equals_the_flat_one(monkeypatch):
+    """Large crowds build the tile-pair list in two levels (strips of the spatial packing first, sfm_pair_list2_kernel).
+    A strip is rejected only if every tile in it would be: same pairs, so the tick is bit-identical to the flat list."""
+    monkeypatch.setenv("SFM_CUTOFF", "1")
+    n = 20000
+    sc = scenarios.make_scenario(n, 909)
+    cfg = default_sfm_config(("acceleration_force", "pedestrian_force"))
+    out = {}
+    for strips in ("0", "1"):
+        monkeypatch.setenv("SFM_STRIPS", strips)
+        eng = SfmEngine(cfg, 0.05)
+        try:
+            eng.upload_state(sc.loc, sc.vel, sc.waypoint, sc.target_speed, sc.radius, None)
+            eng.tick(record=True)
+            assert "sym" in eng.kernel_variant()
+            out[strips] = (eng.forces("total"), eng.velocities())
+        finally:
+            eng.close()
+    assert np.array_equal(out["0"][0], out["1"][0]) and np.array_equal(out["0"][1], out["1"][1])
+    prm = O.OracleParams.from_config(cfg)
+    r = (7000, 7256)
+    per, total, v_new, expo, absum = c_oracle.tick(sc.loc, sc.vel, sc.waypoint, sc.target_speed, sc.radius, np.zeros(n, bool),
+                                                   O.Geometry(), prm, 0.05, rows=r, theta_tol=P.THETA_TOL)
+    P.check_force("total", out["1"][0][r[0]:r[1]], total, absum, expo)
+    P.check_velocity(out["1"][1][r[0]:r[1]], v_new, expo, 0.05)
+
+
 def test_spatial_reordering_is_invisible_to_the_caller(monkeypatch):
-    """Rows are Morton-sorted internally (sfm_upload_state, N >= 8192 or SFM_REORDER=1); every download must come
+    """Rows are spatially packed internally (sfm_upload_state, N >= 2048 or SFM_REORDER=1); every download must come
     back at the caller's index, the waypoint stream must stay keyed by the caller's index, and a scrambled crowd
     must give the same per-pedestrian results as the same crowd in grid order."""
     n = 3000
