@@ -736,10 +736,10 @@ static int sync_perm(SfmHandle* h) {
     return SFM_OK;
 }
 
-// two-level tile-pair list: runs of tps tiles = the x-strips of the spatial packing; worth a launch from ~1000 tiles on
+// two-level tile-pair list: runs of tps tiles = the x-strips of the spatial packing; worth its extra launch from ~2000 tiles on
 static void strip_shape(const SfmHandle* h, int* tps, int* n_strips) {
     *tps = std::max(1, h->strip_rows / WAVE);
-    bool on = h->reordered && h->n_t >= 1024 && *tps >= 8;
+    bool on = h->reordered && h->n_t >= 2048 && *tps >= 8;
     if (const char* ov = getenv("SFM_STRIPS")) on = atoi(ov) != 0;      // tests force either way
     *n_strips = on ? (h->n_t + *tps - 1) / *tps : 0;
 }

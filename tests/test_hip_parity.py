@@ -461,7 +461,7 @@ def test_spatial_reordering_is_invisible_to_the_caller(monkeypatch):
 @pytest.mark.parametrize("n", [500, 9000])
 def test_recorded_run_matches_stepwise_downloads(n, monkeypatch):
     """sfm_run_recorded: frame f is the state before tick f*stride, in the caller's index order (also when the
-    rows are Morton-sorted internally, n = 9000), and recording does not perturb the run."""
+    rows are spatially packed internally, n = 9000), and recording does not perturb the run."""
     monkeypatch.setenv("SFM_RESORT_EVERY", "3")            # the row order changes between the recorded frames
     sc = scenarios.make_scenario(n, 12, n_borders=4, border_len=(5.0, 20.0))
     cfg = default_sfm_config(("acceleration_force", "pedestrian_force", "border_force"))
