@@ -249,6 +249,45 @@ def test_property_checks_at_baseline_size():
         eng.close()
 
 
+@pytest.mark.parametrize("name", ["c3", "c4", "c5"])
+def test_baseline_configs_at_full_size_row_samples(name):
+    """BASELINE configs 3-5 at their full sizes, in the configuration bench.py runs them (spatial packing, tile cutoff,
+    two-level list at c5, geometry kernel): the summed force and v' of three row blocks -- first, middle, last in the
+    caller's order, i.e. scattered over the internal tiles -- against the C oracle, after one tick and, for the state
+    the device reached by itself, after 3 more ticks (re-synchronised: the oracle starts from the device's state)."""
+    sc, forces = scenarios.baseline_scenario(name)
+    cfg = default_sfm_config(forces)
+    prm = O.OracleParams.from_config(cfg)
+    n = sc.n
+    blocks = ((0, 128), (n // 2 - 64, n // 2 + 64), (n - 128, n))
+    eng = SfmEngine(cfg, 0.05)
+    try:
+        if len(sc.borders):
+            eng.set_borders(sc.borders, sc.border_centers, sc.border_lengths)
+        eng.set_static_obstacles(sc.static_obstacles)
+        eng.set_dynamic_obstacles(sc.dynamic_obstacles, sc.dynamic_vel)
+        eng.upload_state(sc.loc, sc.vel, sc.waypoint, sc.target_speed, sc.radius, None)
+        loc, vel, wp3 = sc.loc, sc.vel, sc.waypoint
+        for rnd in range(2):
+            geom = O.Geometry(sc.borders, sc.border_centers, sc.border_lengths, sc.static_obstacles, sc.dynamic_obstacles,
+                              sc.dynamic_vel)
+            eng.tick(integrate=True, record=True)
+            F = eng.forces("total")
+            v = eng.velocities()
+            assert np.isfinite(F).all() and np.isfinite(v).all()
+            for r in blocks:
+                per, total, v_new, expo, absum = c_oracle.tick(loc, vel, wp3, sc.target_speed, sc.radius, np.zeros(n, bool),
+                                                               geom, prm, 0.05, rows=r, theta_tol=P.THETA_TOL)
+                P.check_force("total", F[r[0]:r[1]], total, absum, expo)
+                P.check_velocity(v[r[0]:r[1]], v_new, expo, 0.05)
+            if rnd == 0:
+                eng.run(2, redraw=False)                               # the device carries on by itself ...
+                loc, vel, wp = eng.state()                             # ... and the oracle restarts from where it got to
+                wp3 = np.zeros_like(loc); wp3[:, :2] = wp
+    finally:
+        eng.close()
+
+
 def test_cap_velocity_properties():
     """stateutils.cap_velocity: |v'| <= 1.3*v_target; zero target -> zero velocity."""
     n = 512
