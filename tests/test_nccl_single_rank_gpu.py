@@ -27,7 +27,9 @@ def test_world1_rccl_allgather_on_library_buffer():
     try:
         cfg = default_sfm_config(("acceleration_force", "pedestrian_force", "border_force"))
         sc = scenarios.make_scenario(1500, 31, n_borders=8, border_len=(5.0, 20.0))
-        os.environ["SFM_SYM"] = "0"                     # the ordered kernel is what sharded runs use
+        os.environ["SFM_SYM"] = "0"                     # ordered kernel on both sides: bit-identical
+        os.environ["SFM_REORDER"] = "1"                 # spatial packing on at this size, so that resort() does something
+        os.environ["SFM_RESORT_EVERY"] = "0"            # ... and only when this test says so
         eng = HipShardEngine(cfg, 0.05, device=0)
         st = ShardedStepper(eng, sc, rank=0, world=1)
         (buf, width), = eng.packed()
@@ -38,18 +40,29 @@ def test_world1_rccl_allgather_on_library_buffer():
             st.exchange(force=True)                     # all_gather_into_tensor(buf, buf[chunk]) in place
         eng.synchronize()
         assert not torch.equal(eng.packed()[0][0][:4 * sc.n], before)
+        # the re-pack protocol of a sharded run: all-gather the owner-only per-row arrays (RCCL on the library's
+        # buffers again), re-pack, carry on
+        st._gather(eng.row_data())
+        eng.resort()
+        for _ in range(2):
+            eng.run(1, redraw=True)
+            st.exchange(force=True)
+        eng.synchronize()
         loc, vel, wp = st.gather_state()
         plain = SfmEngine(cfg, 0.05)
         plain.set_borders(sc.borders, sc.border_centers, sc.border_lengths)
         plain.upload_state(sc.loc, sc.vel, sc.waypoint, sc.target_speed, sc.radius, None)
         plain.set_waypoint_stream(sc.seed, sc.world_side, 2.0)
         plain.run(5, redraw=True)
+        plain.resort()
+        plain.run(2, redraw=True)
         loc2, vel2, wp2 = plain.state()
         assert np.array_equal(loc, loc2) and np.array_equal(vel, vel2) and np.array_equal(wp, wp2)
         plain.close()
         eng.close()
     finally:
-        os.environ.pop("SFM_SYM", None)
+        for k in ("SFM_SYM", "SFM_REORDER", "SFM_RESORT_EVERY"):
+            os.environ.pop(k, None)
         dist.destroy_process_group()
 
 
