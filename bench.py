@@ -189,6 +189,18 @@ def main():
             traffic = json.load(f).get(name, {}).get(dominant, {}).get("hbm_bytes")
     except (OSError, ValueError):
         pass
+    # The binding resource of the pair kernel is VALU issue, not HBM: price it too.  One systolic
+    # step of a wave = 64 pairs = 47 plain + 6 DPP + 2 v_bfi + v_cmp/v_cndmask + 5 transcendental ops; with the issue
+    # costs measured on MI355X (tools/valu_microbench.hip: 2.2 / 4.4 / 4.4 / 8.7 / 9.3 cycles) that is ~200 cycles.
+    valu = None
+    if "sym" in variant and "pedestrian_force" in forces and world == 1 and sc.n < 8192:      # no tile cutoff: every pair is evaluated
+        n_t = (sc.n + 63) // 64
+        wave_steps = 64.0 * n_t * (n_t - 1) / 2 + 32.0 * n_t
+        simds, clock_hz, model = 1024, 2.4e9, 200.0
+        spent = kernel_us * 1e-6 * clock_hz * simds / wave_steps
+        valu = {"bound": "valu_issue", "model_cycles_per_wave_step": model, "achieved_cycles_per_wave_step": spent,
+                "frac": model / spent, "wave_steps_per_launch": wave_steps, "simds": simds, "clock_hz": clock_hz,
+                "note": "cycles at the 2.4 GHz peak engine clock (the in-kernel clock read 2.08 GHz under this load: frac ~0.75 at that clock)"}
     barrier()
 
     if rank == 0:
@@ -213,6 +225,8 @@ def main():
                                  "covers / its HIP-event time; traffic = HBM bytes per launch from rocprofv3 PMC passes "
                                  "(profiles/). The operand stream is served on-chip; the binding resource is VALU issue (DESIGN.md 3.4)"},
         }
+        if valu is not None:
+            out["roofline"]["valu_issue"] = valu
         if single_ref is not None:
             out["single_gpu_same_workload"] = {"value": single_ref, "unit": "ticks/s", "speedup": ticks_s / single_ref}
         if world == 1 and not args.no_cpu_baseline:
