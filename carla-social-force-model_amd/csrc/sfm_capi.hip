@@ -26,6 +26,9 @@ hipError_t launch_modes(const TickArgs& a, hipStream_t st);
 struct ReorderBufs { unsigned long long *key64_in, *key64_out; uint32_t *row_a, *row_b, *key32_in, *key32_out; void* temp; size_t temp_bytes; };
 size_t reorder_temp_bytes(int N);
 hipError_t launch_resort(const float4* pk, int N, int strip_rows, const ReorderBufs& b, hipStream_t st);
+hipError_t launch_unpack_rows(const char* block, size_t b_own, size_t b_zv, size_t b_rr, size_t b_cm, int n_pad, float4* pk0,
+                              float4* pk1, float4* own, float2* zv0, float2* zv1, float* radius, uint8_t* crossing, uint32_t* draws,
+                              hipStream_t st);
 hipError_t launch_gather(const uint32_t* src, int N, const float4* pk_in, float4* pk_out, const float2* zv_in, float2* zv_out,
                          const float4* own_in, float4* own_out, const float* rad_in, float* rad_out, const uint8_t* cr_in,
                          uint8_t* cr_out, const uint32_t* dr_in, uint32_t* dr_out, const uint32_t* id_in, uint32_t* id_out,
@@ -47,6 +50,9 @@ struct DevGeo {
     float4* seg = nullptr;
     int K = 0;
     int P = 0;
+    size_t off_cap = 0, pts_cap = 0, ctr_cap = 0;      // grow-only (the dynamic obstacles arrive every tick)
+    char* stage = nullptr;                              // pinned host block the three arrays are copied from, asynchronously
+    size_t stage_cap = 0;
 };
 
 struct SfmHandle {
@@ -85,6 +91,11 @@ struct SfmHandle {
     // tile-granular cutoff of provably negligible pedestrian pairs
     float4* tile_box = nullptr;            // [2][n_t]: the lite cutoff ping-pongs (epilogue k writes the boxes of tick k+1)
     float* tile_vmax = nullptr;
+    char* up_stage = nullptr;              // pinned host block sfm_upload_state assembles the rows in: one async copy to its
+    size_t up_stage_cap = 0;               // device twin, one kernel spreads it over the arrays
+    char* up_block = nullptr;
+    size_t up_block_cap = 0;
+    size_t box_cap = 0, strip_cap = 0, flag_cap = 0;
     float4* strip_box = nullptr;           // [n_t]: boxes / speeds of runs of tiles (two-level list building, n_t >= 1024)
     float* strip_vmax = nullptr;
     int box_cur = 0;
@@ -168,6 +179,17 @@ static hipError_t dev_realloc(T*& p, size_t count) {
     return hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
 }
 
+// grow-only variant for buffers that are re-filled every tick by a host-in-the-loop caller: hipMalloc / hipFree cost
+// tens of microseconds and synchronise the device
+template <typename T>
+static hipError_t dev_reserve(T*& p, size_t& cap, size_t count) {
+    if (count <= cap && p) return hipSuccess;
+    const size_t want = count + count / 2 + 16;
+    hipError_t e = dev_realloc(p, want);
+    cap = (e == hipSuccess) ? want : 0;
+    return e;
+}
+
 static IxConst fold(const SfmInteraction& s) {
     const double log2e = 1.4426950408889634;
     IxConst c{};
@@ -248,6 +270,7 @@ static void free_geo(DevGeo& g) {
     if (g.pts) hipFree(g.pts);
     if (g.ctr) hipFree(g.ctr);
     if (g.seg) hipFree(g.seg);
+    if (g.stage) hipHostFree(g.stage);
     g = DevGeo();
 }
 
@@ -284,6 +307,8 @@ int sfm_destroy(SfmHandle* h) {
     if (h->tile_box) hipFree(h->tile_box);
     if (h->tile_vmax) hipFree(h->tile_vmax);
     if (h->strip_box) hipFree(h->strip_box);
+    if (h->up_stage) hipHostFree(h->up_stage);
+    if (h->up_block) hipFree(h->up_block);
     if (h->strip_vmax) hipFree(h->strip_vmax);
     if (h->work) hipFree(h->work);
     if (h->work_count) hipFree(h->work_count);
@@ -325,14 +350,26 @@ static int set_geo(SfmHandle* h, DevGeo& g, int K, const int32_t* offsets, const
         if (offsets[k + 1] < offsets[k]) return fail(h, SFM_ERR_INVALID, "offsets must be non-decreasing");
     const int P = offsets[K];
     if (P > 0 && (!px || !py)) return fail(h, SFM_ERR_INVALID, "point arrays are NULL");
-    std::vector<float2> pts((size_t)P);
-    for (int p = 0; p < P; ++p) pts[p] = make_float2(px[p], py[p]);
-    HIP_TRY(h, dev_realloc(g.off, (size_t)K + 1));
-    HIP_TRY(h, dev_realloc(g.pts, (size_t)(P > 0 ? P : 1)));
-    HIP_TRY(h, dev_realloc(g.ctr, (size_t)K));
-    HIP_TRY(h, hipMemcpy(g.off, offsets, sizeof(int) * ((size_t)K + 1), hipMemcpyHostToDevice));
-    if (P > 0) HIP_TRY(h, hipMemcpy(g.pts, pts.data(), sizeof(float2) * (size_t)P, hipMemcpyHostToDevice));
-    HIP_TRY(h, hipMemcpy(g.ctr, ctr4.data(), sizeof(float4) * (size_t)K, hipMemcpyHostToDevice));
+    HIP_TRY(h, dev_reserve(g.off, g.off_cap, (size_t)K + 1));
+    HIP_TRY(h, dev_reserve(g.pts, g.pts_cap, (size_t)(P > 0 ? P : 1)));
+    HIP_TRY(h, dev_reserve(g.ctr, g.ctr_cap, (size_t)K));
+    // [ctr | pts | off] assembled in one pinned block, copied asynchronously (the stream was drained above, so the block
+    // is free to overwrite)
+    const size_t b_ctr = 0, b_pts = sizeof(float4) * (size_t)K, b_off = b_pts + sizeof(float2) * (size_t)P;
+    const size_t bytes = b_off + sizeof(int) * ((size_t)K + 1);
+    if (bytes > g.stage_cap) {
+        if (g.stage) { hipHostFree(g.stage); g.stage = nullptr; }
+        const size_t want = bytes + bytes / 2 + 256;
+        HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&g.stage), want, 0));
+        g.stage_cap = want;
+    }
+    memcpy(g.stage + b_ctr, ctr4.data(), sizeof(float4) * (size_t)K);
+    float2* sp = reinterpret_cast<float2*>(g.stage + b_pts);
+    for (int p = 0; p < P; ++p) sp[p] = make_float2(px[p], py[p]);
+    memcpy(g.stage + b_off, offsets, sizeof(int) * ((size_t)K + 1));
+    HIP_TRY(h, hipMemcpyAsync(g.ctr, g.stage + b_ctr, sizeof(float4) * (size_t)K, hipMemcpyHostToDevice, h->stream));
+    if (P > 0) HIP_TRY(h, hipMemcpyAsync(g.pts, g.stage + b_pts, sizeof(float2) * (size_t)P, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(g.off, g.stage + b_off, sizeof(int) * ((size_t)K + 1), hipMemcpyHostToDevice, h->stream));
     g.K = K;
     g.P = P;
     return SFM_OK;
@@ -410,8 +447,9 @@ int sfm_set_dynamic_boxes(SfmHandle* h, int M, const int32_t* offsets, const flo
     for (int k = 0; k < M; ++k) rot[k] = make_float2(yaw_cos[k], yaw_sin[k]);
     HIP_TRY(h, dev_realloc(h->dyn_local, (size_t)(P > 0 ? P : 1)));
     HIP_TRY(h, dev_realloc(h->dyn_rot, (size_t)M));
-    if (P > 0) HIP_TRY(h, hipMemcpy(h->dyn_local, h->dynamics.pts, sizeof(float2) * (size_t)P, hipMemcpyDeviceToDevice));
-    HIP_TRY(h, hipMemcpy(h->dyn_rot, rot.data(), sizeof(float2) * (size_t)M, hipMemcpyHostToDevice));
+    if (P > 0) HIP_TRY(h, hipMemcpyAsync(h->dyn_local, h->dynamics.pts, sizeof(float2) * (size_t)P, hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->dyn_rot, rot.data(), sizeof(float2) * (size_t)M, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));       // `rot` is a local
     HIP_TRY(h, launch_dynamic_boxes(h->dynamics.ctr, h->dynamics.off, h->dyn_local, h->dyn_rot, h->dynamics.pts, M,
                                     h->prm.step_length, 0, h->stream));
     h->dyn_boxes = true;
@@ -469,13 +507,26 @@ int sfm_upload_state(SfmHandle* h, int N, const float* x, const float* y, const 
     h->i_begin = 0; h->i_end = N; h->cur = 0; h->rec_valid = false; h->timing_valid = false;
     h->fsm_on = false;                     // a new crowd: the caller sets the FSM again if it wants it
     if (N == 0) return SFM_OK;
-    std::vector<float4> pk((size_t)n_pad), own((size_t)n_pad, make_float4(0.f, 0.f, 0.f, 0.f));
+    // The rows are assembled in one pinned host block [pk | own | zv | radius | crossing], copied asynchronously in one piece
+    // and spread over the device arrays by one small kernel (a host-in-the-loop caller uploads every tick: no pageable
+    // staging, no allocation, no wait at the end; the stream was drained above, so the block is free to overwrite).
+    const size_t np = (size_t)n_pad;
+    const size_t b_pk = 0, b_own = b_pk + sizeof(float4) * np, b_zv = b_own + sizeof(float4) * np,
+                 b_rr = b_zv + sizeof(float2) * np, b_cm = b_rr + sizeof(float) * np, b_end = b_cm + np;
+    if (b_end > h->up_stage_cap) {
+        if (h->up_stage) { hipHostFree(h->up_stage); h->up_stage = nullptr; }
+        HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&h->up_stage), b_end + b_end / 2, 0));
+        h->up_stage_cap = b_end + b_end / 2;
+    }
+    memset(h->up_stage, 0, b_end);
+    float4* pk = reinterpret_cast<float4*>(h->up_stage + b_pk);
+    float4* own = reinterpret_cast<float4*>(h->up_stage + b_own);
+    float2* zv = reinterpret_cast<float2*>(h->up_stage + b_zv);
+    float* rr = reinterpret_cast<float*>(h->up_stage + b_rr);
+    uint8_t* cm = reinterpret_cast<uint8_t*>(h->up_stage + b_cm);
     // padding rows are ghost pedestrians parked far away at distinct positions: every interaction with them
     // underflows to exactly 0 (exp2 of ~ -1e16), so the symmetric kernel needs no masking
     for (int i = N; i < n_pad; ++i) pk[i] = make_float4(3.0e15f + 1.0e12f * (float)(i - N + 1), 3.0e15f, 0.f, 0.f);
-    std::vector<float2> zv((size_t)n_pad, make_float2(0.f, 0.f));
-    std::vector<float> rr((size_t)n_pad, 0.f);
-    std::vector<uint8_t> cm((size_t)n_pad, 0);
     // spatial order (sfm_reorder.hip): sort by x, cut into strips of strip_rows rows, sort each strip by y, so every
     // 64-row tile is the content of one axis-aligned rectangle.  Stable sorts on order-preserving integer keys: the
     // order is a pure function of the uploaded state, identical on every rank.
@@ -511,16 +562,13 @@ int sfm_upload_state(SfmHandle* h, int N, const float* x, const float* y, const 
         if (radius) rr[s_] = radius[i];
         if (crossing_mask) cm[s_] = crossing_mask[i] ? 1 : 0;
     }
-    for (int b = 0; b < 2; ++b) {
-        HIP_TRY(h, hipMemcpy(h->pk[b], pk.data(), sizeof(float4) * (size_t)n_pad, hipMemcpyHostToDevice));
-        HIP_TRY(h, hipMemcpy(h->zv[b], zv.data(), sizeof(float2) * (size_t)n_pad, hipMemcpyHostToDevice));
-    }
-    HIP_TRY(h, hipMemcpy(h->own, own.data(), sizeof(float4) * (size_t)n_pad, hipMemcpyHostToDevice));
-    HIP_TRY(h, hipMemcpy(h->radius, rr.data(), sizeof(float) * (size_t)n_pad, hipMemcpyHostToDevice));
-    HIP_TRY(h, hipMemcpy(h->crossing, cm.data(), (size_t)n_pad, hipMemcpyHostToDevice));
-    HIP_TRY(h, hipMemset(h->draws, 0, sizeof(uint32_t) * (size_t)n_pad));
+    HIP_TRY(h, dev_reserve(h->up_block, h->up_block_cap, b_end));
+    HIP_TRY(h, hipMemcpyAsync(h->up_block, h->up_stage, b_end, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, launch_unpack_rows(h->up_block, b_own, b_zv, b_rr, b_cm, n_pad, h->pk[0], h->pk[1], h->own, h->zv[0], h->zv[1],
+                                  h->radius, h->crossing, h->draws, h->stream));
     if (h->reordered) {
-        HIP_TRY(h, hipMemcpy(h->ids, h->perm.data(), sizeof(uint32_t) * (size_t)N, hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpyAsync(h->ids, h->perm.data(), sizeof(uint32_t) * (size_t)N, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));          // perm is pageable and may be resized by the next upload
         if (n_pad > h->sort_cap) {
             HIP_TRY(h, dev_realloc(h->own2, (size_t)n_pad)); HIP_TRY(h, dev_realloc(h->radius2, (size_t)n_pad));
             HIP_TRY(h, dev_realloc(h->crossing2, (size_t)n_pad)); HIP_TRY(h, dev_realloc(h->draws2, (size_t)n_pad));
@@ -530,10 +578,10 @@ int sfm_upload_state(SfmHandle* h, int N, const float* x, const float* y, const 
             HIP_TRY(h, hipMalloc(&h->sort_temp, h->sort_temp_bytes > 0 ? h->sort_temp_bytes : 16));
             h->sort_cap = n_pad;
         }
-        HIP_TRY(h, hipMemset(h->own2, 0, sizeof(float4) * (size_t)n_pad));
-        HIP_TRY(h, hipMemset(h->radius2, 0, sizeof(float) * (size_t)n_pad));
-        HIP_TRY(h, hipMemset(h->crossing2, 0, (size_t)n_pad));
-        HIP_TRY(h, hipMemset(h->draws2, 0, sizeof(uint32_t) * (size_t)n_pad));
+        HIP_TRY(h, hipMemsetAsync(h->own2, 0, sizeof(float4) * np, h->stream));
+        HIP_TRY(h, hipMemsetAsync(h->radius2, 0, sizeof(float) * np, h->stream));
+        HIP_TRY(h, hipMemsetAsync(h->crossing2, 0, np, h->stream));
+        HIP_TRY(h, hipMemsetAsync(h->draws2, 0, sizeof(uint32_t) * np, h->stream));
     }
     h->ticks_since_sort = 0;
     h->perm_stale = false;
@@ -543,15 +591,19 @@ int sfm_upload_state(SfmHandle* h, int N, const float* x, const float* y, const 
     if (!z3 && !rad && h->dpp_dir != 0 && h->sym_mode != 0 && need * sizeof(float2) <= ((size_t)16 << 30)) {
         if (need > h->slab_cap) { HIP_TRY(h, dev_realloc(h->slab, need)); h->slab_cap = need; }
         if (h->n_t > h->tile_cap) { HIP_TRY(h, dev_realloc(h->tile_flag, (size_t)h->n_t)); h->tile_cap = h->n_t; }
-        HIP_TRY(h, hipMemset(h->tile_flag, 0, sizeof(int) * (size_t)h->n_t));
+        HIP_TRY(h, hipMemsetAsync(h->tile_flag, 0, sizeof(int) * (size_t)h->n_t, h->stream));
     }
     // cutoff bookkeeping: per-tile box / max speed, and the work list of the symmetric kernel
     h->r_max = 0.f;
     if (rad) for (int i = 0; i < N; ++i) h->r_max = std::fmax(h->r_max, radius[i]);
-    HIP_TRY(h, dev_realloc(h->tile_box, (size_t)h->n_t * 2));
-    HIP_TRY(h, dev_realloc(h->tile_vmax, (size_t)h->n_t * 2));
-    HIP_TRY(h, dev_realloc(h->strip_box, (size_t)h->n_t));
-    HIP_TRY(h, dev_realloc(h->strip_vmax, (size_t)h->n_t));
+    if ((size_t)h->n_t > h->box_cap) {
+        const size_t want = (size_t)h->n_t + (size_t)h->n_t / 2 + 4;
+        HIP_TRY(h, dev_realloc(h->tile_box, want * 2));
+        HIP_TRY(h, dev_realloc(h->tile_vmax, want * 2));
+        HIP_TRY(h, dev_realloc(h->strip_box, want));
+        HIP_TRY(h, dev_realloc(h->strip_vmax, want));
+        h->box_cap = want;
+    }
     h->box_cur = 0;
     h->boxes_valid = false;
     {

@@ -58,6 +58,32 @@ __global__ void sfm_gather_rows_kernel(const uint32_t* __restrict__ src, int N, 
     id_out[s] = id_in[o];
 }
 
+// sfm_upload_state: the rows arrive as one block [pk | own | zv | radius | crossing]; one thread per row spreads it over the
+// device arrays (both halves of the ping-pong buffers) and zeroes the draw counter.
+__global__ void sfm_unpack_rows_kernel(const char* __restrict__ block, size_t b_own, size_t b_zv, size_t b_rr, size_t b_cm,
+                                       int n_pad, float4* __restrict__ pk0, float4* __restrict__ pk1, float4* __restrict__ own,
+                                       float2* __restrict__ zv0, float2* __restrict__ zv1, float* __restrict__ radius,
+                                       uint8_t* __restrict__ crossing, uint32_t* __restrict__ draws) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_pad) return;
+    const float4 p = reinterpret_cast<const float4*>(block)[s];
+    pk0[s] = p; pk1[s] = p;
+    own[s] = reinterpret_cast<const float4*>(block + b_own)[s];
+    const float2 z = reinterpret_cast<const float2*>(block + b_zv)[s];
+    zv0[s] = z; zv1[s] = z;
+    radius[s] = reinterpret_cast<const float*>(block + b_rr)[s];
+    crossing[s] = reinterpret_cast<const uint8_t*>(block + b_cm)[s];
+    draws[s] = 0u;
+}
+
+hipError_t launch_unpack_rows(const char* block, size_t b_own, size_t b_zv, size_t b_rr, size_t b_cm, int n_pad, float4* pk0,
+                              float4* pk1, float4* own, float2* zv0, float2* zv1, float* radius, uint8_t* crossing, uint32_t* draws,
+                              hipStream_t st) {
+    hipLaunchKernelGGL(sfm_unpack_rows_kernel, dim3((n_pad + 255) / 256), dim3(256), 0, st, block, b_own, b_zv, b_rr, b_cm, n_pad,
+                       pk0, pk1, own, zv0, zv1, radius, crossing, draws);
+    return hipGetLastError();
+}
+
 struct ReorderBufs {
     unsigned long long *key64_in, *key64_out;
     uint32_t *row_a, *row_b, *key32_in, *key32_out;   // the final order is in row_b: row_b[s] = old row that moves to row s
