@@ -43,6 +43,8 @@ using namespace sfm;
 
 static thread_local std::string g_create_error;
 
+constexpr int GEO_SLICES_MAX = 8;
+
 struct DevGeo {
     int* off = nullptr;
     float2* pts = nullptr;
@@ -500,7 +502,7 @@ int sfm_upload_state(SfmHandle* h, int N, const float* x, const float* y, const 
         HIP_TRY(h, dev_realloc(h->draws, (size_t)n_pad));
         HIP_TRY(h, dev_realloc(h->ids, (size_t)n_pad));
         HIP_TRY(h, dev_realloc(h->rec, (size_t)n_pad * 18));
-        HIP_TRY(h, dev_realloc(h->geo, (size_t)n_pad * 6));
+        HIP_TRY(h, dev_realloc(h->geo, (size_t)n_pad * 6 * GEO_SLICES_MAX));
         h->cap = n_pad;
     }
     h->N = N; h->N_pad = n_pad; h->z3 = z3; h->rad = rad;
@@ -720,6 +722,11 @@ static void fill_args(SfmHandle* h, TickArgs& a, uint32_t flags) {
     const bool any_geo = (p.enabled[SFM_FORCE_BORDER] && h->borders.K > 0) || (p.enabled[SFM_FORCE_STATIC_OBSTACLE] && h->statics.K > 0) ||
                          (p.enabled[SFM_FORCE_DYNAMIC_OBSTACLE] && h->dynamics.K > 0);
     a.geo = any_geo ? h->geo : nullptr;
+    {   // a handful of tiles cannot fill 256 CUs: split each tile's polylines over up to 8 workgroups
+        const int tiles = std::max(1, (h->i_end + WAVE - 1) / WAVE - h->i_begin / WAVE);
+        a.geo_slices = tiles <= 32 ? GEO_SLICES_MAX : tiles <= 64 ? 4 : tiles <= 128 ? 2 : 1;
+        if (const char* ov = getenv("SFM_GEO_SLICES")) a.geo_slices = std::min(GEO_SLICES_MAX, std::max(1, atoi(ov)));
+    }
     const bool cut = p.enabled[SFM_FORCE_PEDESTRIAN] && h->tile_box && h->N <= 64 * 64 * WAVE &&
                      (h->cut_mode == 1 || (h->cut_mode < 0 && h->N >= 8192)) && p.pedestrian.gamma > 0.f && p.pedestrian.lambda >= 0.f;
     // "lite" cutoff (no work list): the pair kernel's workgroups test their own tile pair and the symmetric epilogue

@@ -67,7 +67,9 @@ struct TickArgs {
     uint32_t* draws;          // waypoint draw counters
     const uint32_t* ids;      // caller's index of the pedestrian in each row (spatial reordering); null = identity
     float* rec;               // optional per-force record, layout [6][3][N]
-    float* geo;               // geometry forces of this tick, layout [6][N_pad]: {fbx,fby,fsx,fsy,fdx,fdy}; null = none
+    float* geo;               // geometry forces of this tick, layout [geo_slices][6][N_pad]: {fbx,fby,fsx,fsy,fdx,fdy}; null = none
+    int geo_slices;           // few tiles (small crowds): the polylines of a tile are split over this many workgroups, each
+                              // leaving a partial sum; the consumer adds them in slice order
     int N, N_pad, i_begin, i_end;
     uint32_t flags;
     // parameters

@@ -313,21 +313,21 @@ __device__ __forceinline__ void geo_item(const TickArgs& a, const GeoLane& me, c
 // The tile's view of the geometry: bounding box of its pedestrians, centre / half diagonal, largest chord skip.
 struct GeoTile { float x0, y0, x1, y1, cx, cy, half_diag, skip_max; };
 
-// One pass of a wave over its polylines (k = base + 16 lane + wave).  64 at a time, one per lane, they are tested
+// One pass of a wave over its polylines (k = base + n_gwaves lane + gwave; n_gwaves = 16 waves x the slices of the tile).  64 at a time, one per lane, they are tested
 // against the tile; each survivor's parameters are read out of its lane with v_readlane and the reference's exact
 // per-pedestrian test runs lane-parallel.  SCAN = false: the first GEO_ITEMS kept polylines go to the wave's list;
 // returns how many were kept.  SCAN = true (list overflow): the kept polylines beyond GEO_ITEMS are scanned on the spot.
 template <bool RAD, bool SCAN>
 __device__ __forceinline__ int geo_find(const TickArgs& a, const GeoLane& me, const GeoTile& tb, GeoItem* list, float2* row,
-                                        int lane, int wave, float (&f)[6]) {
+                                        int lane, int gwave, int n_gwaves, float (&f)[6]) {
     int n_found = 0;                                                   // uniform
 #pragma unroll
     for (int kind = 0; kind < 3; ++kind) {
         const Geo& g = kind == 0 ? a.borders : kind == 1 ? a.statics : a.dynamics;
         if (!(kind == 0 ? a.en_border : kind == 1 ? a.en_static : a.en_dynamic)) continue;
         const float thr2 = kind == 1 ? a.stat.thr2 : a.dyn.thr2;
-        for (int base = 0; base < g.K; base += GEO_BLOCK) {
-            const int k = base + lane * GEO_WAVES + wave;
+        for (int base = 0; base < g.K; base += WAVE * n_gwaves) {
+            const int k = base + lane * n_gwaves + gwave;
             bool near = false;
             float4 c = make_float4(0.f, 0.f, 0.f, 0.f), s0 = c, s1 = c;
             int o0 = 0, o1 = 0;
@@ -412,7 +412,9 @@ __global__ __launch_bounds__(GEO_BLOCK) void sfm_geometry_kernel(const TickArgs 
     float f[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
     // ---- phase 1: find
-    const int n_found = geo_find<RAD, false>(a, me, tb, s_item[wave], row, lane, wave, f);
+    const int slice = blockIdx.y;                                      // small crowds: the tile's polylines are split over
+    const int gwave = slice * GEO_WAVES + wave, n_gwaves = GEO_WAVES * (int)gridDim.y;   // gridDim.y workgroups
+    const int n_found = geo_find<RAD, false>(a, me, tb, s_item[wave], row, lane, gwave, n_gwaves, f);
     if (lane == 0) s_count[wave] = min(n_found, GEO_ITEMS);
     __syncthreads();
 
@@ -434,7 +436,7 @@ __global__ __launch_bounds__(GEO_BLOCK) void sfm_geometry_kernel(const TickArgs 
     }
     // ---- list overflow (a tile whose pedestrians are spread over the whole map): this wave walks its polylines
     // again and scans, on the spot, the kept ones that did not fit
-    if (n_found > GEO_ITEMS) geo_find<RAD, true>(a, me, tb, s_item[wave], row, lane, wave, f);
+    if (n_found > GEO_ITEMS) geo_find<RAD, true>(a, me, tb, s_item[wave], row, lane, gwave, n_gwaves, f);
 #pragma unroll
     for (int q = 0; q < 6; ++q) s_acc[wave][q][lane] = f[q];
     __syncthreads();
@@ -444,7 +446,7 @@ __global__ __launch_bounds__(GEO_BLOCK) void sfm_geometry_kernel(const TickArgs 
         for (int w = 0; w < GEO_WAVES; ++w) v += s_acc[w][wave][lane];
         if (wave >= 4) v *= a.dyn.negA;
         else if (wave >= 2) v *= a.stat.negA;
-        a.geo[(size_t)wave * a.N_pad + i] = v;
+        a.geo[((size_t)slice * 6 + wave) * a.N_pad + i] = v;
     }
 }
 
@@ -820,8 +822,11 @@ __global__ __launch_bounds__(BLOCK) void sfm_tick_kernel(const TickArgs a) {
         float fbx = 0.f, fby = 0.f, fsx = 0.f, fsy = 0.f, fdx = 0.f, fdy = 0.f;
         if (a.geo) {                                // border / obstacle forces from sfm_geometry_kernel
             const size_t np_ = (size_t)a.N_pad;
-            fbx = a.geo[0 * np_ + i]; fby = a.geo[1 * np_ + i]; fsx = a.geo[2 * np_ + i];
-            fsy = a.geo[3 * np_ + i]; fdx = a.geo[4 * np_ + i]; fdy = a.geo[5 * np_ + i];
+            for (int sl = 0; sl < a.geo_slices; ++sl) {
+                const float* gsl = a.geo + (size_t)sl * 6 * np_ + i;
+                fbx += gsl[0 * np_]; fby += gsl[1 * np_]; fsx += gsl[2 * np_];
+                fsy += gsl[3 * np_]; fdx += gsl[4 * np_]; fdy += gsl[5 * np_];
+            }
         }
 
         // AccelerationForce (forces.py:46-53, stateutils.py:7-15)
@@ -1288,8 +1293,11 @@ __global__ __launch_bounds__(EPI_BLOCK) void sfm_sym_epilogue_kernel(const TickA
     float fbx = 0.f, fby = 0.f, fsx = 0.f, fsy = 0.f, fdx = 0.f, fdy = 0.f;
     if (a.geo) {
         const size_t np_ = (size_t)a.N_pad;
-        fbx = a.geo[0 * np_ + i]; fby = a.geo[1 * np_ + i]; fsx = a.geo[2 * np_ + i];
-        fsy = a.geo[3 * np_ + i]; fdx = a.geo[4 * np_ + i]; fdy = a.geo[5 * np_ + i];
+        for (int sl = 0; sl < a.geo_slices; ++sl) {
+            const float* gsl = a.geo + (size_t)sl * 6 * np_ + i;
+            fbx += gsl[0 * np_]; fby += gsl[1 * np_]; fsx += gsl[2 * np_];
+            fsy += gsl[3 * np_]; fdx += gsl[4 * np_]; fdy += gsl[5 * np_];
+        }
     }
     const float x = st.x, y = st.y, vx = st.z, vy = st.w, ts = o.z;
     float wx = o.x, wy = o.y;
@@ -1430,8 +1438,8 @@ hipError_t launch_geometry(bool rad, const TickArgs& a, hipStream_t st) {
     const int n_local = a.i_end - a.i_begin;
     if (n_local <= 0) return hipSuccess;
     const int grid = ((a.i_end + WAVE - 1) >> 6) - (a.i_begin >> 6);      // tiles overlapping the shard
-    if (rad) hipLaunchKernelGGL((sfm_geometry_kernel<true>), dim3(grid), dim3(GEO_BLOCK), 0, st, a);
-    else hipLaunchKernelGGL((sfm_geometry_kernel<false>), dim3(grid), dim3(GEO_BLOCK), 0, st, a);
+    if (rad) hipLaunchKernelGGL((sfm_geometry_kernel<true>), dim3(grid, a.geo_slices), dim3(GEO_BLOCK), 0, st, a);
+    else hipLaunchKernelGGL((sfm_geometry_kernel<false>), dim3(grid, a.geo_slices), dim3(GEO_BLOCK), 0, st, a);
     return hipGetLastError();
 }
 

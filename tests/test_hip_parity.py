@@ -182,10 +182,14 @@ def test_radius_and_z_variants_vs_oracle(variant, reorder, monkeypatch):
         eng.close()
 
 
+@pytest.mark.parametrize("slices", ["1", "8"])
 @pytest.mark.parametrize("use_radius", [False, True])
-def test_dense_geometry_overflows_the_per_wave_lists(use_radius):
-    """A small square packed with polylines: every wave of the geometry kernel keeps more polylines than its LDS
-    list holds (32), so the on-the-spot scan of the overflow pass and the list path both contribute."""
+def test_dense_geometry_overflows_the_per_wave_lists(use_radius, slices, monkeypatch):
+    """A small square packed with polylines.  With one workgroup per tile (SFM_GEO_SLICES=1) every wave of the geometry
+    kernel keeps more polylines than its LDS list holds (32), so the on-the-spot scan of the overflow pass and the list
+    path both contribute; with the default for a small crowd the polylines are split over 8 workgroups per tile and the
+    consumer adds 8 partial sums."""
+    monkeypatch.setenv("SFM_GEO_SLICES", slices)
     n = 200
     sc = scenarios.make_scenario(n, 4242, n_borders=900, n_static=700, n_dynamic=40, border_len=(4.0, 12.0))
     cfg = default_sfm_config()
