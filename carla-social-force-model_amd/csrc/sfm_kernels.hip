@@ -1446,7 +1446,7 @@ hipError_t launch_geometry(bool rad, const TickArgs& a, hipStream_t st) {
 hipError_t launch_sym_pair(const TickArgs& a, const SymArgs& sa, hipStream_t st) {
     if (a.N <= 1 || !a.en_ped) return hipSuccess;
     if (sa.work) {
-        // cutoff on: compact the tile pairs that have to be evaluated, then a resident grid strides over them
+        // cutoff on: compact the tile pairs that have to be evaluated, then a resident grid takes contiguous runs of them
         hipError_t e = hipMemsetAsync(const_cast<int*>(sa.work_count), 0, sizeof(int), st);
         if (e != hipSuccess) return e;
         const bool whole = sa.t_lo == 0 && sa.t_hi == sa.n_t;      // a shard also looks at partners behind it

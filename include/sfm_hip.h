@@ -119,10 +119,11 @@ int sfm_upload_state(SfmHandle* h, int N,
 /* Rows [i_begin, i_end) this handle computes and integrates (pedestrian index sharding across GPUs,
  * SURVEY.md section 8e).  Default after sfm_upload_state: [0, N).  All N pedestrians stay resident as the
  * j-operand set; after each tick the caller all-gathers the packed state (below) across ranks.
- * Rows are the library's internal order: for N >= 2048 sfm_upload_state sorts the pedestrians by the Hilbert-curve
- * index of their 1 m cell (a pure function of the uploaded state, so every rank derives the same order), which
- * makes a row block a compact region.  Every download writes a row's result at the CALLER's index of that
- * pedestrian; entries of pedestrians outside the shard are left untouched. */
+ * Rows are the library's internal order: for N >= 2048 sfm_upload_state packs the pedestrians spatially (sorted by x
+ * into strips, each strip sorted by y: every 64-row tile is one rectangle of the map; a pure function of the uploaded
+ * state, so every rank derives the same order), which makes a row block a vertical slab of the map.  A shard whose
+ * bounds are multiples of 64 can use the symmetric pair kernel.  Every download writes a row's result at the CALLER's
+ * index of that pedestrian; entries of pedestrians outside the shard are left untouched. */
 int sfm_set_shard(SfmHandle* h, int i_begin, int i_end);
 
 /* Counter-based waypoint stream of the synthetic scenarios: on arrival within `arrive_threshold`

@@ -1,5 +1,5 @@
 """Diagnostic: geometry / pair kernel time along a c3 run, (a) with the periodic device re-sort, (b) without it,
-(c) with a host re-upload (= host-side Hilbert sort) every 64 ticks instead.  Run under rocprofv3 --kernel-trace."""
+(c) with a host re-upload (= the host-side packing of sfm_upload_state) every 64 ticks instead.  Run under rocprofv3 --kernel-trace."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
