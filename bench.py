@@ -15,6 +15,8 @@ Workloads (--workload overrides the default):
             state per tick, plus a gather of the waypoint arrays and an identical re-pack on every rank each 64 ticks.
             Rank 0 also times 40 ticks of the SAME workload on one GPU before the run ("single_gpu_same_workload")
             so the strong-scaling speed-up can be read off one line.
+  SFM_BENCH_REHEARSAL=1 (development only): every rank on cuda:0, collectives over gloo -- runs the multi-rank flow end to
+            end on a one-GPU box; its timings mean nothing.
 """
 import argparse
 import json
@@ -126,9 +128,17 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
+    # rehearsal on a one-GPU box (never used by the driver): SFM_BENCH_REHEARSAL=1 puts every rank on cuda:0 and moves the
+    # collectives over gloo, so that the multi-rank flow (shards, exchange, re-pack protocol) runs end to end
+    rehearsal = os.environ.get("SFM_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
 
     name = args.workload if args.workload != "auto" else ("c2" if world == 1 else "c5")
     sc, forces = scenarios.baseline_scenario(name)
