@@ -161,3 +161,51 @@ def test_two_shards_with_row_repacking_match_the_whole_crowd_run(path, monkeypat
     assert all(("sym" in e.engine.kernel_variant()) == (path == "symmetric") for e in ranks)
     for e in ranks:
         e.close()
+
+
+def _two_rank_worker(rank, world, port, out, ticks, every):
+    import torch.distributed as dist
+    from carla_social_force_model_amd.stepper import HipShardEngine, ShardedStepper
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SFM_CUTOFF="1")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cfg = default_sfm_config(("acceleration_force", "pedestrian_force", "border_force"))
+        sc = scenarios.make_scenario(6000, 4711, n_borders=25, border_len=(5.0, 25.0))
+        eng = HipShardEngine(cfg, 0.05, device=0)
+        st = ShardedStepper(eng, sc, rank=rank, world=world, resort_every=every)
+        st.step(ticks)
+        eng.synchronize()
+        variant = eng.engine.kernel_variant()
+        loc, vel, wp = st.gather_state()
+        if rank == 0:
+            np.savez(out, loc=loc, vel=vel, wp=wp, sym=np.array("sym" in variant))
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_processes_share_the_gpu_and_match_the_single_process_run(tmp_path, monkeypatch):
+    """The real multi-rank flow -- two processes, ShardedStepper + HipShardEngine, symmetric kernel on tile-aligned
+    shards, the per-tick exchange and two re-packs (rows change rank) -- with both ranks on the one GPU of this box and
+    the collectives over gloo.  Against one process stepping the whole crowd: rounding-level agreement."""
+    import torch.multiprocessing as mp
+    from carla_social_force_model_amd.stepper import HipShardEngine, ShardedStepper
+    ticks, every = 20, 8
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "two_ranks.npz")
+    mp.spawn(_two_rank_worker, args=(2, port, out, ticks, every), nprocs=2, join=True)
+    z = np.load(out)
+    assert bool(z["sym"])
+    monkeypatch.setenv("SFM_CUTOFF", "1")
+    monkeypatch.setenv("SFM_RESORT_EVERY", str(every))
+    cfg = default_sfm_config(("acceleration_force", "pedestrian_force", "border_force"))
+    sc = scenarios.make_scenario(6000, 4711, n_borders=25, border_len=(5.0, 25.0))
+    eng = HipShardEngine(cfg, 0.05, device=0)
+    st = ShardedStepper(eng, sc)
+    st.step(ticks)
+    loc, vel, wp = st.gather_state()
+    eng.close()
+    assert np.allclose(z["loc"], loc, rtol=2e-5, atol=2e-5) and np.allclose(z["vel"], vel, rtol=2e-5, atol=2e-5)
+    assert np.array_equal(z["wp"], wp)
