@@ -44,6 +44,42 @@ __global__ void k(float* out, int iters, float seed, unsigned long long* stamps)
         } else if (OP == 11) {  // v_fmaak (literal constant) x8
             a0 = fmaf(a0, a1, 0.12345f); a1 = fmaf(a1, a2, 0.22345f); a2 = fmaf(a2, a3, 0.32345f); a3 = fmaf(a3, a4, 0.42345f);
             a4 = fmaf(a4, a5, 0.52345f); a5 = fmaf(a5, a6, 0.62345f); a6 = fmaf(a6, a7, 0.72345f); a7 = fmaf(a7, a0, 0.82345f);
+        } else if (OP >= 30 && OP <= 45) {  // operand-form sweep of v_fma / v_mul / v_add (which forms run at full rate?)
+            const float sc = seed * 3.0f;   // lands in an SGPR
+#define X8(stmt) { float& a = a0; stmt } { float& a = a1; stmt } { float& a = a2; stmt } { float& a = a3; stmt } \
+                 { float& a = a4; stmt } { float& a = a5; stmt } { float& a = a6; stmt } { float& a = a7; stmt }
+            if (OP == 30) { X8(asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a) : "v"(c), "v"(d));) }
+            if (OP == 31) { X8(asm volatile("v_fma_f32 %0, %1, %0, %2" : "+v"(a) : "s"(sc), "v"(d));) }
+            if (OP == 32) { X8(asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a) : "s"(sc), "v"(d));) }
+            if (OP == 33) { X8(asm volatile("v_fma_f32 %0, %0, %1, 0.5" : "+v"(a) : "v"(c));) }
+            if (OP == 34) { X8(asm volatile("v_fma_f32 %0, %0, %1, 0.5" : "+v"(a) : "s"(sc));) }
+            if (OP == 35) { X8(asm volatile("v_mul_f32_e32 %0, %1, %0" : "+v"(a) : "s"(sc));) }
+            if (OP == 36) { X8(asm volatile("v_fma_f32 %0, -%0, %1, %2" : "+v"(a) : "v"(c), "v"(d));) }
+            if (OP == 37) { X8(asm volatile("v_add_f32_e64 %0, |%0|, 1.0" : "+v"(a));) }
+            if (OP == 38) { X8(asm volatile("v_mul_f32_e64 %0, %0, -%1" : "+v"(a) : "v"(c));) }
+            if (OP == 39) { X8(asm volatile("v_fmamk_f32 %0, %0, 0x3dfcd35b, %1" : "+v"(a) : "v"(c));) }
+            if (OP == 40) { X8(asm volatile("v_sub_f32_e32 %0, %1, %0" : "+v"(a) : "s"(sc));) }
+            if (OP == 41) { X8(asm volatile("v_add_f32_e32 %0, 1.0, %0" : "+v"(a));) }
+            if (OP == 42) { X8(asm volatile("v_max_i32 %0, %0, %1" : "+v"(a) : "v"(c));) }
+            if (OP == 43) { X8(asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a) : "v"(c), "s"(sc));) }
+            if (OP == 44) { X8(asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a) : "v"(c) : );) }
+            if (OP == 45) { X8(asm volatile("v_mul_f32_e32 %0, 0.5, %0" : "+v"(a));) }
+#undef X8
+        } else if (OP >= 12 && OP <= 21) {  // single instructions, forced encodings, 8 independent accumulators
+            const float sc = seed * 3.0f;   // lands in an SGPR
+#define X8(stmt) { float& a = a0; stmt } { float& a = a1; stmt } { float& a = a2; stmt } { float& a = a3; stmt } \
+                 { float& a = a4; stmt } { float& a = a5; stmt } { float& a = a6; stmt } { float& a = a7; stmt }
+            if (OP == 12) { X8(asm volatile("v_fmaak_f32 %0, %0, %1, 0x3dfcd35b" : "+v"(a) : "v"(c));) }
+            if (OP == 13) { X8(asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a) : "v"(c), "s"(sc));) }
+            if (OP == 14) { X8(asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a) : "v"(c), "v"(d));) }
+            if (OP == 15) { X8(asm volatile("v_mul_f32 %0, 0x3f800347, %0" : "+v"(a));) }
+            if (OP == 16) { X8(asm volatile("v_mul_f32 %0, %1, %0" : "+v"(a) : "v"(c));) }
+            if (OP == 17) { X8(asm volatile("v_bfi_b32 %0, %1, %0, %2" : "+v"(a) : "s"(0x7fffffff), "v"(c));) }
+            if (OP == 18) { X8(asm volatile("v_max_f32 %0, %0, %1" : "+v"(a) : "v"(c));) }
+            if (OP == 19) { X8(asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a) : "v"(c));) }
+            if (OP == 20) { X8(asm volatile("v_cmp_lt_f32 vcc, %0, %1" :: "v"(a), "v"(c) : "vcc");) }
+            if (OP == 21) { X8(asm volatile("v_sub_f32 %0, %0, %1" : "+v"(a) : "v"(c));) }
+#undef X8
         } else if (OP == 6) {  // mixed: 4 fma + 4 exp interleaved
             a0 = fmaf(a0, c, d); a1 = __builtin_amdgcn_exp2f(a1); a2 = fmaf(a2, c, d); a3 = __builtin_amdgcn_exp2f(a3);
             a4 = fmaf(a4, c, d); a5 = __builtin_amdgcn_exp2f(a5); a6 = fmaf(a6, c, d); a7 = __builtin_amdgcn_exp2f(a7);
@@ -80,6 +116,13 @@ int main() {
         run<0>("v_fma_f32", w, 1); run<1>("v_pk_fma_f32", w, 2); run<4>("v_pk_mul_f32", w, 2); run<2>("v_exp_f32", w, 1);
         run<3>("v_rsq_f32", w, 1); run<5>("cmp+cndmask", w, 1); run<6>("fma+exp mix", w, 1);
         run<7>("dpp wave_rol:1", w, 1); run<8>("dpp row_ror:1", w, 1); run<9>("dpp quad_perm", w, 1); run<10>("ds_bpermute", w, 1); run<11>("v_fmaak lit", w, 1);
+        run<12>("v_fmaak asm", w, 1); run<13>("v_fma sgpr", w, 1); run<14>("v_fmac", w, 1); run<15>("v_mul literal", w, 1);
+        run<16>("v_mul", w, 1); run<17>("v_bfi", w, 1); run<18>("v_max", w, 1); run<19>("v_cndmask", w, 1); run<20>("v_cmp", w, 1);
+        run<21>("v_sub", w, 1);
+        run<30>("fma v,v,v", w, 1); run<31>("fma s,v,v", w, 1); run<32>("fma v,s,v", w, 1); run<33>("fma v,v,0.5", w, 1);
+        run<34>("fma v,s,0.5", w, 1); run<35>("mul_e32 s,v", w, 1); run<36>("fma -v,v,v", w, 1); run<37>("add |v|,1.0", w, 1);
+        run<38>("mul_e64 v,-v", w, 1); run<39>("v_fmamk", w, 1); run<40>("sub_e32 s,v", w, 1); run<41>("add_e32 1.0,v", w, 1);
+        run<42>("v_max_i32", w, 1); run<43>("fma v,v,s", w, 1); run<44>("cndmask only", w, 1); run<45>("mul_e32 0.5,v", w, 1);
     }
     return 0;
 }
