@@ -44,7 +44,7 @@ __global__ void k(float* out, int iters, float seed, unsigned long long* stamps)
         } else if (OP == 11) {  // v_fmaak (literal constant) x8
             a0 = fmaf(a0, a1, 0.12345f); a1 = fmaf(a1, a2, 0.22345f); a2 = fmaf(a2, a3, 0.32345f); a3 = fmaf(a3, a4, 0.42345f);
             a4 = fmaf(a4, a5, 0.52345f); a5 = fmaf(a5, a6, 0.62345f); a6 = fmaf(a6, a7, 0.72345f); a7 = fmaf(a7, a0, 0.82345f);
-        } else if (OP >= 30 && OP <= 45) {  // operand-form sweep of v_fma / v_mul / v_add (which forms run at full rate?)
+        } else if (OP >= 30 && OP <= 47) {  // operand-form sweep of v_fma / v_mul / v_add (which forms run at full rate?)
             const float sc = seed * 3.0f;   // lands in an SGPR
 #define X8(stmt) { float& a = a0; stmt } { float& a = a1; stmt } { float& a = a2; stmt } { float& a = a3; stmt } \
                  { float& a = a4; stmt } { float& a = a5; stmt } { float& a = a6; stmt } { float& a = a7; stmt }
@@ -63,6 +63,8 @@ __global__ void k(float* out, int iters, float seed, unsigned long long* stamps)
             if (OP == 42) { X8(asm volatile("v_max_i32 %0, %0, %1" : "+v"(a) : "v"(c));) }
             if (OP == 43) { X8(asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a) : "v"(c), "s"(sc));) }
             if (OP == 44) { X8(asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a) : "v"(c) : );) }
+            if (OP == 46) { X8(asm volatile("v_add_f32_dpp %0, %0, %1 wave_rol:1 row_mask:0xf bank_mask:0xf" : "+v"(a) : "v"(d));) }
+            if (OP == 47) { X8(asm volatile("v_add_f32_dpp %0, %0, %1 row_ror:1 row_mask:0xf bank_mask:0xf" : "+v"(a) : "v"(d));) }
             if (OP == 45) { X8(asm volatile("v_mul_f32_e32 %0, 0.5, %0" : "+v"(a));) }
 #undef X8
         } else if (OP >= 12 && OP <= 21) {  // single instructions, forced encodings, 8 independent accumulators
@@ -123,6 +125,7 @@ int main() {
         run<34>("fma v,s,0.5", w, 1); run<35>("mul_e32 s,v", w, 1); run<36>("fma -v,v,v", w, 1); run<37>("add |v|,1.0", w, 1);
         run<38>("mul_e64 v,-v", w, 1); run<39>("v_fmamk", w, 1); run<40>("sub_e32 s,v", w, 1); run<41>("add_e32 1.0,v", w, 1);
         run<42>("v_max_i32", w, 1); run<43>("fma v,v,s", w, 1); run<44>("cndmask only", w, 1); run<45>("mul_e32 0.5,v", w, 1);
+        run<46>("add_dpp wave_rol", w, 1); run<47>("add_dpp row_ror", w, 1);
     }
     return 0;
 }
