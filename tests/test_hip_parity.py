@@ -216,10 +216,61 @@ def test_dense_geometry_overflows_the_per_wave_lists(use_radius, slices, monkeyp
             P.check_force(name, eng.forces(name), per[name], diag[name][1], diag[name][0])
         # Hundreds of obstacle terms of opposite directions per pedestrian: |F| is far below the sum of the
         # magnitudes, so v' = cap(v + dt F) inherits dt * 1e-5 * (that sum), not 1e-5 |v'|.  Stated here, used only here.
-        got, ref = np.asarray(eng.velocities(), dtype=np.float64), v_new
         summed = sum(np.nan_to_num(diag[name][1]) for name in O.FORCE_NAMES)
-        allow = P.RTOL * (np.linalg.norm(ref, axis=1) + 0.05 * summed) + 0.05 * np.nan_to_num(diag["total"][0]) * 1.001 + 1e-12
-        assert (np.linalg.norm(got - ref, axis=1) <= allow).all()
+        P.check_velocity_conditioned(eng.velocities(), v_new, diag["total"][0], summed, 0.05)
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_randomised_small_scenarios(seed, monkeypatch):
+    """Sixteen seeded draws of everything at once: crowd size (1 .. 900, tile edges included), how many borders / static /
+    dynamic obstacles (zero included), border lengths, radius on or off, a z spread or none, which forces are enabled,
+    a crossing mask, the internal row packing forced on or off, the tile cutoff on or off.  Every enabled force and v'
+    against the oracle."""
+    rng = np.random.default_rng(9000 + seed)
+    n = int(rng.choice([1, 2, 63, 64, 65, 127, 128, 129, 255, 256, 257, int(rng.integers(3, 900))]))
+    n = {0: 1, 5: 2, 10: 3}.get(seed, n)                 # the smallest crowds, explicitly
+    nb, ns, nd = (int(rng.integers(0, 30)) for _ in range(3))
+    if seed % 5 == 0 and seed != 10:
+        nb = ns = nd = 0
+    z_spread = float(rng.choice([0.0, 0.0, 1.5]))
+    sc = scenarios.make_scenario(n, 100 + seed, n_borders=nb, n_static=ns, n_dynamic=nd, z_spread=z_spread,
+                                 border_len=(float(rng.uniform(1.0, 5.0)), float(rng.uniform(6.0, 30.0))))
+    forces = [f for f in O.FORCE_NAMES if rng.random() < 0.8] or ["pedestrian_force"]
+    if nb == 0 and "border_force" in forces:
+        forces.remove("border_force")          # the reference's BorderForce cannot be built without borders
+    if not forces:
+        forces = ["acceleration_force"]
+    cfg = default_sfm_config(tuple(forces))
+    cfg["use_ped_radius"] = bool(rng.random() < 0.4)
+    sc.radius = np.float32(rng.uniform(0.2, 0.45, n)).astype(np.float64)
+    crossing = rng.random(n) < 0.2
+    monkeypatch.setenv("SFM_REORDER", str(int(rng.random() < 0.5)))
+    monkeypatch.setenv("SFM_CUTOFF", str(int(rng.random() < 0.5)))
+    prm = O.OracleParams.from_config(cfg)
+    geom = O.Geometry(sc.borders, sc.border_centers, sc.border_lengths, sc.static_obstacles, sc.dynamic_obstacles,
+                      sc.dynamic_vel)
+    diag = {}
+    with np.errstate(all="ignore"):
+        per, total, _ = O.tick_forces(sc.loc, sc.vel, sc.waypoint, sc.target_speed, sc.radius, crossing, geom, prm,
+                                      theta_tol=P.THETA_TOL, tie_rel=P.TIE_REL, diag=diag)
+    v_new = O.new_velocities(sc.vel, total, sc.target_speed, 0.05)
+    eng = SfmEngine(cfg, 0.05)
+    try:
+        if nb:
+            eng.set_borders(sc.borders, sc.border_centers, sc.border_lengths)
+        eng.set_static_obstacles(sc.static_obstacles)
+        eng.set_dynamic_obstacles(sc.dynamic_obstacles, sc.dynamic_vel)
+        eng.upload_state(sc.loc, sc.vel, sc.waypoint, sc.target_speed, sc.radius, crossing)
+        eng.tick(record=True)
+        for name in forces:
+            P.check_force(name, eng.forces(name), per[name], diag[name][1], diag[name][0])
+        # fast vehicles next to pedestrians: the conditioned bound (see _parity.check_velocity_conditioned); at most a
+        # handful of pedestrians per draw may need more than the plain 1e-5 |v'|
+        summed = sum(np.nan_to_num(diag[name][1]) for name in forces)
+        needed = P.check_velocity_conditioned(eng.velocities(), v_new, diag["total"][0], summed, 0.05)
+        assert needed <= max(2, n // 100)
     finally:
         eng.close()
 
