@@ -102,6 +102,9 @@ struct SfmHandle {
     float* strip_vmax = nullptr;
     int box_cur = 0;
     bool boxes_valid = false;
+    int geo_slices_override = 0;           // SFM_GEO_SLICES / SFM_STRIPS / SFM_DEBUG_STEPS, read once at sfm_create (tests, probes)
+    int strips_override = -1;
+    int debug_steps = -1;
     uint32_t* work = nullptr;
     int* work_count = nullptr;
     size_t work_cap = 0;
@@ -253,6 +256,12 @@ int sfm_create(const SfmParams* params, int device_id, SfmHandle** out) {
     if (ov) h->cut_mode = atoi(ov);
     ov = getenv("SFM_REORDER");
     if (ov) h->reorder_mode = atoi(ov);
+    ov = getenv("SFM_GEO_SLICES");
+    if (ov) h->geo_slices_override = std::min(GEO_SLICES_MAX, std::max(1, atoi(ov)));
+    ov = getenv("SFM_STRIPS");
+    if (ov) h->strips_override = atoi(ov) != 0 ? 1 : 0;
+    ov = getenv("SFM_DEBUG_STEPS");
+    if (ov) h->debug_steps = atoi(ov);
     ov = getenv("SFM_RESORT_EVERY");
     if (ov) h->resort_every = atoi(ov);
     if (getenv("SFM_STAMPS")) {
@@ -725,7 +734,7 @@ static void fill_args(SfmHandle* h, TickArgs& a, uint32_t flags) {
     {   // a handful of tiles cannot fill 256 CUs: split each tile's polylines over up to 8 workgroups
         const int tiles = std::max(1, (h->i_end + WAVE - 1) / WAVE - h->i_begin / WAVE);
         a.geo_slices = tiles <= 32 ? GEO_SLICES_MAX : tiles <= 64 ? 4 : tiles <= 128 ? 2 : 1;
-        if (const char* ov = getenv("SFM_GEO_SLICES")) a.geo_slices = std::min(GEO_SLICES_MAX, std::max(1, atoi(ov)));
+        if (h->geo_slices_override > 0) a.geo_slices = h->geo_slices_override;
     }
     const bool cut = p.enabled[SFM_FORCE_PEDESTRIAN] && h->tile_box && h->N <= 64 * 64 * WAVE &&
                      (h->cut_mode == 1 || (h->cut_mode < 0 && h->N >= 8192)) && p.pedestrian.gamma > 0.f && p.pedestrian.lambda >= 0.f;
@@ -799,7 +808,7 @@ static int sync_perm(SfmHandle* h) {
 static void strip_shape(const SfmHandle* h, int* tps, int* n_strips) {
     *tps = std::max(1, h->strip_rows / WAVE);
     bool on = h->reordered && h->n_t >= 2048 && *tps >= 8;
-    if (const char* ov = getenv("SFM_STRIPS")) on = atoi(ov) != 0;      // tests force either way
+    if (h->strips_override >= 0) on = h->strips_override != 0;       // SFM_STRIPS: tests force either way
     *n_strips = on ? (h->n_t + *tps - 1) / *tps : 0;
 }
 
@@ -873,7 +882,7 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags) {
             ++launches;
         }
         if (sym) {
-            SymArgs sa{h->slab, h->tile_flag, h->n_t, slab_stride(h->n_t), h->dpp_dir, getenv("SFM_DEBUG_STEPS") ? atoi(getenv("SFM_DEBUG_STEPS")) : -1,
+            SymArgs sa{h->slab, h->tile_flag, h->n_t, slab_stride(h->n_t), h->dpp_dir, h->debug_steps,
                        (a.tile_box && !lite) ? h->work : nullptr, (a.tile_box && !lite) ? h->work_count : nullptr,
                        lite ? a.tile_box : nullptr, lite ? a.tile_vmax : nullptr, a.cut_scale, a.cut_pad, h->stamps,
                        h->strip_box, h->strip_vmax, tps, n_strips, h->i_begin / WAVE, (h->i_end + WAVE - 1) / WAVE};
