@@ -16,6 +16,8 @@
 // No MFMA: the pair body is ~60 dependent VALU ops with 5 transcendentals, not a contraction.
 #include "sfm_device.h"
 
+#include <algorithm>
+
 namespace sfm {
 
 __device__ __forceinline__ float rsq(float x) { return __builtin_amdgcn_rsqf(x); }
@@ -1459,7 +1461,10 @@ hipError_t launch_sym_pair(const TickArgs& a, const SymArgs& sa, hipStream_t st)
                            const_cast<uint32_t*>(sa.work), const_cast<int*>(sa.work_count));
         e = hipGetLastError();
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(sfm_pair_sym_kernel, dim3(256 * 8 * 2), dim3(BLOCK), 0, st, a.pk_cur, a.ped, sa);
+        // a few times more workgroups than fit at once (8 per CU): short runs interleave better with the geometry kernel's
+        // workgroups and even out the tail; measured best 4x at 256 tiles, 16x from 1024 tiles on
+        const int rounds = std::min(16, std::max(2, sa.n_t / 64));
+        hipLaunchKernelGGL(sfm_pair_sym_kernel, dim3(256 * 8 * rounds), dim3(BLOCK), 0, st, a.pk_cur, a.ped, sa);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(sfm_pair_sym_kernel, dim3(sa.n_t, sa.n_t / 2 + 1), dim3(BLOCK), 0, st, a.pk_cur, a.ped, sa);
