@@ -488,6 +488,36 @@ def test_tile_cutoff_keeps_parity(order, sym, monkeypatch):
             assert times["grid"] < 0.8 * times["scrambled"], times
 
 
+@pytest.mark.parametrize("strips", ["0", "1"])
+def test_device_resident_run_is_reproducible_bit_for_bit(strips, monkeypatch):
+    """A device-resident run with everything on -- tile-pair list (its ORDER comes from atomics and varies from run to
+    run), geometry kernel, periodic re-pack, waypoint redraw -- must give the same bits every time: each slab row is written
+    exactly once and every sum has a fixed order."""
+    monkeypatch.setenv("SFM_CUTOFF", "1")
+    monkeypatch.setenv("SFM_RESORT_EVERY", "16")
+    monkeypatch.setenv("SFM_STRIPS", strips)
+    n = 9000
+    sc = scenarios.make_scenario(n, 31337, n_borders=60, n_static=20, n_dynamic=8, border_len=(5.0, 30.0))
+    cfg = default_sfm_config()
+    runs = []
+    for _ in range(2):
+        eng = SfmEngine(cfg, 0.05)
+        try:
+            eng.set_borders(sc.borders, sc.border_centers, sc.border_lengths)
+            eng.set_static_obstacles(sc.static_obstacles)
+            eng.set_dynamic_obstacles(sc.dynamic_obstacles, sc.dynamic_vel)
+            eng.upload_state(sc.loc, sc.vel, sc.waypoint, sc.target_speed, sc.radius, None)
+            eng.set_waypoint_stream(sc.seed, sc.world_side, 2.0)
+            eng.run(70, redraw=True)
+            assert "sym" in eng.kernel_variant()
+            runs.append(eng.state())
+        finally:
+            eng.close()
+    for a, b in zip(*runs):
+        assert np.isfinite(a).all() and np.array_equal(a, b)
+    assert np.linalg.norm(runs[0][0] - sc.loc) > 10.0           # and the crowd did walk
+
+
 def test_two_level_pair_list_equals_the_flat_one(monkeypatch):
     """Large crowds build the tile-pair list in two levels (strips of the spatial packing first, sfm_pair_list2_kernel).
     A strip is rejected only if every tile in it would be: same pairs, so the tick is bit-identical to the flat list."""
