@@ -237,6 +237,13 @@ def main():
         }
         if valu is not None:
             out["roofline"]["valu_issue"] = valu
+        if "pedestrian_force" in forces:
+            # SURVEY.md section 8d, "algorithmic flops": ~65 fp32 VALU ops per ORDERED pedestrian pair against the
+            # 7.9e13 lane-ops/s of the chip (256 CUs x 4 SIMDs x 32 lanes/clk x 2.4 GHz); the symmetric kernel evaluates an
+            # unordered pair once, which this definition credits as two
+            ops = 65.0 * n * (n - 1.0) * ticks_s
+            out["roofline"]["valu_algorithmic"] = {"ops_per_ordered_pair": 65.0, "achieved_ops_per_s": ops, "peak_ops_per_s": 7.9e13,
+                                                   "frac": ops / 7.9e13 / world}
         if single_ref is not None:
             out["single_gpu_same_workload"] = {"value": single_ref, "unit": "ticks/s", "speedup": ticks_s / single_ref}
         if world == 1 and not args.no_cpu_baseline:
