@@ -736,6 +736,9 @@ static void fill_args(SfmHandle* h, TickArgs& a, uint32_t flags) {
         a.geo_slices = tiles <= 32 ? GEO_SLICES_MAX : tiles <= 64 ? 4 : tiles <= 128 ? 2 : 1;
         if (h->geo_slices_override > 0) a.geo_slices = h->geo_slices_override;
     }
+    // device-side vehicles move on at the end of an integrating tick: extra workgroups of the tick's last kernel
+    a.adv = DynAdvance{h->dynamics.ctr, h->dynamics.off, h->dyn_local, h->dyn_rot, h->dynamics.pts,
+                       (h->dyn_boxes && (flags & SFM_TICK_INTEGRATE)) ? h->dynamics.K : 0, h->prm.step_length, 0};
     const bool cut = p.enabled[SFM_FORCE_PEDESTRIAN] && h->tile_box && h->N <= 64 * 64 * WAVE &&
                      (h->cut_mode == 1 || (h->cut_mode < 0 && h->N >= 8192)) && p.pedestrian.gamma > 0.f && p.pedestrian.lambda >= 0.f;
     // "lite" cutoff (no work list): the pair kernel's workgroups test their own tile pair and the symmetric epilogue
@@ -905,7 +908,7 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags) {
         else h->boxes_valid = false;
         if (h->fsm_on) h->sim_time += h->prm.step_length;
         // CARLA-free runs: the vehicles move between ticks (run_simulation.py:77-95)
-        if (h->dyn_boxes && (flags & SFM_TICK_INTEGRATE) && h->dynamics.K > 0) {
+        if (a.adv.M > 0 && n_local <= 0) {          // a rank without rows still has to move its copy of the vehicles
             HIP_TRY(h, launch_dynamic_boxes(h->dynamics.ctr, h->dynamics.off, h->dyn_local, h->dyn_rot, h->dynamics.pts,
                                             h->dynamics.K, h->prm.step_length, 1, h->stream));
             ++launches;

@@ -55,6 +55,19 @@ struct FsmArgs {
     int despawn_on_arrival;
 };
 
+// Device-side vehicles (sfm_set_dynamic_boxes): after a tick's forces are computed the centres move by dt * v and the rings
+// are regenerated.  The extra workgroups of the tick's last kernel do it (block index >= block0); M = 0: nothing to do.
+struct DynAdvance {
+    float4* ctr;              // [M] {cx, cy, vx, vy}
+    const int* off;           // [M+1]
+    const float2* local;      // [P] ring points in the vehicle frame
+    const float2* rot;        // [M] {cos yaw, sin yaw}
+    float2* pts;              // [P] ring points in the world frame (what the geometry kernel reads)
+    int M;
+    float dt;
+    int block0;
+};
+
 struct TickArgs {
     // packed j-operand state, N_pad records (padding rows are never selected)
     const float4* pk_cur;     // {x, y, vx, vy}
@@ -68,6 +81,7 @@ struct TickArgs {
     const uint32_t* ids;      // caller's index of the pedestrian in each row (spatial reordering); null = identity
     float* rec;               // optional per-force record, layout [6][3][N]
     float* geo;               // geometry forces of this tick, layout [geo_slices][6][N_pad]: {fbx,fby,fsx,fsy,fdx,fdy}; null = none
+    DynAdvance adv;
     int geo_slices;           // few tiles (small crowds): the polylines of a tile are split over this many workgroups, each
                               // leaving a partial sum; the consumer adds them in slice order
     int N, N_pad, i_begin, i_end;

@@ -142,6 +142,22 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// One wave moves vehicle k by dt * v and regenerates its ring p = c + R(yaw) u (obstacles.py:297-329 without the simulator).
+__device__ __forceinline__ void advance_vehicle(const DynAdvance& d, int k, int lane, bool advance) {
+    float4 c = d.ctr[k];
+    if (advance) {
+        c.x = fmaf(d.dt, c.z, c.x);
+        c.y = fmaf(d.dt, c.w, c.y);
+        if (lane == 0) d.ctr[k] = c;
+    }
+    const float2 r = d.rot[k];                     // {cos yaw, sin yaw}
+    const int o1 = d.off[k + 1];
+    for (int p = d.off[k] + lane; p < o1; p += WAVE) {
+        const float2 u = d.local[p];
+        d.pts[p] = make_float2(fmaf(r.x, u.x, fmaf(-r.y, u.y, c.x)), fmaf(r.y, u.x, fmaf(r.x, u.y, c.y)));
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------
 // provably negligible tile pairs
 // ------------------------------------------------------------------------------------------------------
@@ -597,6 +613,11 @@ __global__ __launch_bounds__(BLOCK) void sfm_tick_kernel(const TickArgs a) {
     const int tid = threadIdx.x;
     const int lane = tid & (WAVE - 1);
     const int wave = uniform(tid >> 6);
+    if (a.adv.M > 0 && (int)blockIdx.x >= a.adv.block0) {            // the extra workgroups: vehicles move on (nobody in this
+        const int k = ((int)blockIdx.x - a.adv.block0) * WAVES_PER_BLOCK + wave;   // launch reads their rings)
+        if (k < a.adv.M) advance_vehicle(a.adv, k, lane, true);
+        return;
+    }
     const int ibase = a.i_begin + (TEAM == 1 ? (blockIdx.x * WAVES_PER_BLOCK + wave) : blockIdx.x) * IPW;   // uniform
     const int N = a.N;
 
@@ -1202,6 +1223,11 @@ __global__ __launch_bounds__(EPI_BLOCK) void sfm_sym_epilogue_kernel(const TickA
     const int tid = threadIdx.x;
     const int lane = tid & (WAVE - 1);
     const int wave = uniform(tid >> 6);
+    if (a.adv.M > 0 && (int)blockIdx.x >= a.adv.block0) {            // the extra workgroups: vehicles move on
+        const int k = ((int)blockIdx.x - a.adv.block0) * EPI_WAVES + wave;
+        if (k < a.adv.M) advance_vehicle(a.adv, k, lane, true);
+        return;
+    }
     const int t = sa.t_lo + blockIdx.x;
     const int N = a.N;
     const int i_end = a.i_end;                             // rows of this handle end here (whole crowd: N)
@@ -1365,24 +1391,14 @@ __global__ __launch_bounds__(EPI_BLOCK) void sfm_sym_epilogue_kernel(const TickA
     }
 }
 
-// Dynamic obstacles on the device (obstacles.py:297-329 without the simulator): one thread per vehicle moves
-// the centre by dt*v (advance != 0) and regenerates its ring p = c + R(yaw) u.
-__global__ void sfm_dynamic_boxes_kernel(float4* __restrict__ ctr, const int* __restrict__ off,
-                                         const float2* __restrict__ local, const float2* __restrict__ rot,
-                                         float2* __restrict__ pts, int M, float dt, int advance) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+// Dynamic obstacles on the device (obstacles.py:297-329 without the simulator): one wave per vehicle moves the centre
+// by dt*v (advance != 0) and regenerates its ring p = c + R(yaw) u, the lanes over the ring points.
+__global__ __launch_bounds__(BLOCK) void sfm_dynamic_boxes_kernel(float4* __restrict__ ctr, const int* __restrict__ off,
+                                                                  const float2* __restrict__ local, const float2* __restrict__ rot,
+                                                                  float2* __restrict__ pts, int M, float dt, int advance) {
+    const int k = blockIdx.x * WAVES_PER_BLOCK + (int)(threadIdx.x >> 6);
     if (k >= M) return;
-    float4 c = ctr[k];
-    if (advance) {
-        c.x = fmaf(dt, c.z, c.x);
-        c.y = fmaf(dt, c.w, c.y);
-        ctr[k] = c;
-    }
-    const float2 r = rot[k];                       // {cos yaw, sin yaw}
-    for (int p = off[k]; p < off[k + 1]; ++p) {
-        const float2 u = local[p];
-        pts[p] = make_float2(fmaf(r.x, u.x, fmaf(-r.y, u.y, c.x)), fmaf(r.y, u.x, fmaf(r.x, u.y, c.y)));
-    }
+    advance_vehicle(DynAdvance{ctr, off, local, rot, pts, M, dt, 0}, k, threadIdx.x & (WAVE - 1), advance != 0);
 }
 
 // get_arrived_peds (pedestrian_simulation.py:88-97) on the current device state.
@@ -1405,7 +1421,10 @@ static hipError_t launch_one(const TickArgs& a, hipStream_t st) {
     if (n_local <= 0) return hipSuccess;
     const int per_block = IPW * (WAVES_PER_BLOCK / TEAM);
     const int grid = (n_local + per_block - 1) / per_block;
-    hipLaunchKernelGGL((sfm_tick_kernel<IPW, Z3, RAD, TEAM>), dim3(grid), dim3(BLOCK), 0, st, a);
+    TickArgs b = a;
+    b.adv.block0 = grid;
+    const int extra = a.adv.M > 0 ? (a.adv.M + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK : 0;
+    hipLaunchKernelGGL((sfm_tick_kernel<IPW, Z3, RAD, TEAM>), dim3(grid + extra), dim3(BLOCK), 0, st, b);
     return hipGetLastError();
 }
 
@@ -1486,7 +1505,10 @@ hipError_t launch_strip_bounds(const float4* box, const float* vmax, int n_t, in
 
 hipError_t launch_sym_epilogue(const TickArgs& a, const SymArgs& sa, hipStream_t st) {
     if (a.N <= 0) return hipSuccess;
-    hipLaunchKernelGGL((sfm_sym_epilogue_kernel<false>), dim3(sa.t_hi - sa.t_lo), dim3(EPI_BLOCK), 0, st, a, sa);
+    TickArgs b = a;
+    b.adv.block0 = sa.t_hi - sa.t_lo;
+    const int extra = a.adv.M > 0 ? (a.adv.M + EPI_WAVES - 1) / EPI_WAVES : 0;
+    hipLaunchKernelGGL((sfm_sym_epilogue_kernel<false>), dim3(sa.t_hi - sa.t_lo + extra), dim3(EPI_BLOCK), 0, st, b, sa);
     return hipGetLastError();
 }
 
@@ -1507,7 +1529,8 @@ int probe_dpp_direction(hipStream_t st) {
 hipError_t launch_dynamic_boxes(float4* ctr, const int* off, const float2* local, const float2* rot, float2* pts, int M,
                                 float dt, int advance, hipStream_t st) {
     if (M <= 0) return hipSuccess;
-    hipLaunchKernelGGL(sfm_dynamic_boxes_kernel, dim3((M + 63) / 64), dim3(64), 0, st, ctr, off, local, rot, pts, M, dt, advance);
+    hipLaunchKernelGGL(sfm_dynamic_boxes_kernel, dim3((M + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), dim3(BLOCK), 0, st, ctr, off, local,
+                       rot, pts, M, dt, advance);
     return hipGetLastError();
 }
 
