@@ -1240,7 +1240,38 @@ __global__ __launch_bounds__(EPI_BLOCK) void sfm_sym_epilogue_kernel(const TickA
 
     // 1. slab column sums
     float2 acc = make_float2(0.f, 0.f);
-    if (a.en_ped && a.tile_box) {
+    if (a.en_ped && a.tile_box && sa.n_strips > 0) {
+        // cutoff on, large crowd: wave w owns strips w, w+16, ... (sfm_pair_list2_kernel's two levels: a negligible strip
+        // holds only negligible tiles); its lanes test the tiles of a surviving strip and only the rows of evaluated tile
+        // pairs are read (fixed order, deterministic)
+        const float2* col = sa.slab + i;
+        const float4 bt = a.tile_box[t];
+        const float vt = a.tile_vmax[t];
+        for (int s = wave; s < sa.n_strips; s += EPI_WAVES) {
+            if (tiles_negligible(bt, vt, sa.sbox[s], sa.svmax[s], a.ped.lam, a.cut_scale, a.cut_pad)) continue;   // uniform
+            for (int q0 = 0; q0 < sa.tps; q0 += WAVE) {
+                const int u0 = s * sa.tps + q0, u = u0 + lane;
+                bool keep = false;
+                if (q0 + lane < sa.tps && u < sa.n_t)
+                    keep = !tiles_negligible(bt, vt, a.tile_box[u], a.tile_vmax[u], a.ped.lam, a.cut_scale, a.cut_pad);
+                unsigned long long m = __ballot(keep);
+                while (m) {                               // up to four independent row loads in flight
+                    float2 v[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        v[q] = make_float2(0.f, 0.f);
+                        if (m) {
+                            const int b = __ffsll((long long)m) - 1;
+                            m &= m - 1;
+                            v[q] = col[(size_t)(u0 + b) * sa.stride];
+                        }
+                    }
+                    acc.x += (v[0].x + v[1].x) + (v[2].x + v[3].x);
+                    acc.y += (v[0].y + v[1].y) + (v[2].y + v[3].y);
+                }
+            }
+        }
+    } else if (a.en_ped && a.tile_box) {
         // cutoff on: wave w owns partner tiles w, w+16, ...; its lanes test 64 of them at a time and only the rows of
         // evaluated tile pairs are read (ascending order, deterministic)
         const float2* col = sa.slab + i;

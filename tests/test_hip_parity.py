@@ -519,8 +519,10 @@ def test_device_resident_run_is_reproducible_bit_for_bit(strips, monkeypatch):
 
 
 def test_two_level_pair_list_equals_the_flat_one(monkeypatch):
-    """Large crowds build the tile-pair list in two levels (strips of the spatial packing first, sfm_pair_list2_kernel).
-    A strip is rejected only if every tile in it would be: same pairs, so the tick is bit-identical to the flat list."""
+    """Large crowds build the tile-pair list in two levels (strips of the spatial packing first, sfm_pair_list2_kernel) and
+    the epilogue walks a pedestrian's partner tiles the same way.  A strip is rejected only if every tile in it would be:
+    the same pairs are evaluated; only the ORDER in which the epilogue adds a pedestrian's partner rows differs from the
+    flat form, i.e. the two ticks agree to rounding."""
     monkeypatch.setenv("SFM_CUTOFF", "1")
     n = 20000
     sc = scenarios.make_scenario(n, 909)
@@ -536,7 +538,9 @@ def test_two_level_pair_list_equals_the_flat_one(monkeypatch):
             out[strips] = (eng.forces("total"), eng.velocities())
         finally:
             eng.close()
-    assert np.array_equal(out["0"][0], out["1"][0]) and np.array_equal(out["0"][1], out["1"][1])
+    scale = np.abs(out["0"][0]).max()
+    assert np.abs(out["0"][0] - out["1"][0]).max() <= 4e-7 * scale        # a few ulps of the largest force
+    assert np.allclose(out["0"][1], out["1"][1], rtol=1e-6, atol=1e-7)
     prm = O.OracleParams.from_config(cfg)
     r = (7000, 7256)
     per, total, v_new, expo, absum = c_oracle.tick(sc.loc, sc.vel, sc.waypoint, sc.target_speed, sc.radius, np.zeros(n, bool),
