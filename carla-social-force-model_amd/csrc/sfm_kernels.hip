@@ -1023,33 +1023,52 @@ __global__ __launch_bounds__(BLOCK) void sfm_pair_list2_kernel(const float4* __r
         const bool hit = s < sa.n_strips && !tiles_negligible(bt, vt, sa.sbox[min(s, sa.n_strips - 1)], sa.svmax[min(s, sa.n_strips - 1)],
                                                               lam, sa.cut_scale, sa.cut_pad);
         unsigned long long ms = __ballot(hit);
-        while (ms) {
-            const int s0 = (sb + __ffsll((long long)ms) - 1) * sa.tps;      // first tile of a surviving strip
+        // the surviving strips, one trip of 64 tiles at a time; the next trip's boxes are loaded before this one is examined
+        int s0 = -1, q0 = 0;                                   // current trip: tiles s0 + q0 + lane
+        auto advance = [&](int& ns0, int& nq0) {              // -> the trip after (ns0, nq0); ns0 = -1: none left
+            if (ns0 >= 0 && nq0 + WAVE < sa.tps) { nq0 += WAVE; return; }
+            if (!ms) { ns0 = -1; return; }
+            ns0 = (sb + __ffsll((long long)ms) - 1) * sa.tps;
             ms &= ms - 1;
-            for (int q0 = 0; q0 < sa.tps; q0 += WAVE) {
-                const int tb = s0 + q0 + lane;
-                bool keep = (q0 + lane) < sa.tps && tb < n_t;
-                uint32_t item = 0u;
-                if (keep) {
-                    int shift = tb - bx;
-                    if (shift < 0) shift += n_t;
-                    if (shift == 0) {
-                        keep = (bx - sa.t_lo) < ((sa.t_hi - sa.t_lo + 1) >> 1);
-                    } else {
-                        const bool own = tb >= sa.t_lo && tb < sa.t_hi;
-                        if (own) keep = shift <= (n_t >> 1) && !(!(n_t & 1) && shift == (n_t >> 1) && bx >= (n_t >> 1));
-                        if (keep) keep = !tiles_negligible(bt, vt, box[tb], vmax[tb], lam, sa.cut_scale, sa.cut_pad);
-                        item = own ? 0u : WORK_ONE_SIDED;
-                    }
-                    item |= (uint32_t)bx | ((uint32_t)shift << 16);
+            nq0 = 0;
+        };
+        auto fetch = [&](int fs0, int fq0, float4& fb, float& fv, bool& ok) {
+            const int tb = fs0 + fq0 + lane;
+            ok = fs0 >= 0 && (fq0 + lane) < sa.tps && tb < n_t;
+            if (ok) { fb = box[tb]; fv = vmax[tb]; }
+        };
+        advance(s0, q0);
+        float4 cb = make_float4(0.f, 0.f, 0.f, 0.f), nb = cb;
+        float cv = 0.f, nv = 0.f;
+        bool c_ok = false, n_ok = false;
+        fetch(s0, q0, cb, cv, c_ok);
+        while (s0 >= 0) {
+            int ns0 = s0, nq0 = q0;
+            advance(ns0, nq0);
+            fetch(ns0, nq0, nb, nv, n_ok);
+            const int tb = s0 + q0 + lane;
+            bool keep = c_ok;
+            uint32_t item = 0u;
+            if (keep) {
+                int shift = tb - bx;
+                if (shift < 0) shift += n_t;
+                if (shift == 0) {
+                    keep = (bx - sa.t_lo) < ((sa.t_hi - sa.t_lo + 1) >> 1);
+                } else {
+                    const bool own = tb >= sa.t_lo && tb < sa.t_hi;
+                    if (own) keep = shift <= (n_t >> 1) && !(!(n_t & 1) && shift == (n_t >> 1) && bx >= (n_t >> 1));
+                    if (keep) keep = !tiles_negligible(bt, vt, cb, cv, lam, sa.cut_scale, sa.cut_pad);
+                    item = own ? 0u : WORK_ONE_SIDED;
                 }
-                const unsigned long long mk = __ballot(keep);
-                if (mk) {
-                    if (n_buf + WAVE > BUF) flush();
-                    if (keep) buf[n_buf + __popcll(mk & ((1ull << lane) - 1ull))] = item;
-                    n_buf += __popcll(mk);
-                }
+                item |= (uint32_t)bx | ((uint32_t)shift << 16);
             }
+            const unsigned long long mk = __ballot(keep);
+            if (mk) {
+                if (n_buf + WAVE > BUF) flush();
+                if (keep) buf[n_buf + __popcll(mk & ((1ull << lane) - 1ull))] = item;
+                n_buf += __popcll(mk);
+            }
+            s0 = ns0; q0 = nq0; cb = nb; cv = nv; c_ok = n_ok;
         }
     }
     flush();
