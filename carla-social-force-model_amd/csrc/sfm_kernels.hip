@@ -1086,8 +1086,9 @@ __global__ __launch_bounds__(BLOCK) void sfm_pair_list2_kernel(const float4* __r
 // coalesced 512-B row per side, to slab[partner tile][pedestrian] -- every slab entry is written exactly
 // once per tick, and the epilogue kernel sums a pedestrian's n_t entries in a fixed order (deterministic).
 // Padding rows are "ghost" pedestrians parked ~3e15 m away at distinct positions: their terms underflow to
-// exactly 0, so no masking is needed.  Planar crowds without use_ped_radius only; anything else, and
-// sharded runs, use the ordered kernel above.
+// exactly 0, so no masking is needed.  Planar crowds without use_ped_radius only (whole crowd, or a shard of whole
+// tiles under the tile-pair list, where a pair with another rank's tile is evaluated one-sided); anything else uses
+// the ordered kernel above.
 __device__ __forceinline__ float rot1(float v) {
     const int b = __float_as_int(v);   // old == src: lets the register allocator rotate in place (no pre-clear move)
     return __int_as_float(__builtin_amdgcn_update_dpp(b, b, 0x134 /* wave_rol:1 */, 0xf, 0xf, false));
