@@ -17,8 +17,8 @@
 namespace sfm {
 hipError_t launch_tick(int ipw, int team, bool z3, bool rad, const TickArgs& a, hipStream_t st);
 hipError_t launch_arrived(const float4* pk, const float4* own, int N, float thr2, uint8_t* mask, hipStream_t st);
-hipError_t launch_sym_pair(const TickArgs& a, const SymArgs& sa, hipStream_t st);
-hipError_t launch_sym_epilogue(const TickArgs& a, const SymArgs& sa, hipStream_t st);
+hipError_t launch_sym_pair(bool rad, const TickArgs& a, const SymArgs& sa, hipStream_t st);
+hipError_t launch_sym_epilogue(bool rad, const TickArgs& a, const SymArgs& sa, hipStream_t st);
 hipError_t launch_strip_bounds(const float4* box, const float* vmax, int n_t, int tps, int n_strips, float4* sbox, float* svmax,
                                hipStream_t st);
 hipError_t launch_geometry(bool rad, const TickArgs& a, hipStream_t st);
@@ -599,7 +599,7 @@ int sfm_upload_state(SfmHandle* h, int N, const float* x, const float* y, const 
     // slab of the symmetric path: n_t x (n_t*64) float2 (8.6 GB at N = 262 144), up to 16 GiB of the 288 GB
     h->n_t = (N + WAVE - 1) / WAVE;
     const size_t need = (size_t)h->n_t * (size_t)slab_stride(h->n_t);
-    if (!z3 && !rad && h->dpp_dir != 0 && h->sym_mode != 0 && need * sizeof(float2) <= ((size_t)16 << 30)) {
+    if (!z3 && h->dpp_dir != 0 && h->sym_mode != 0 && need * sizeof(float2) <= ((size_t)16 << 30)) {
         if (need > h->slab_cap) { HIP_TRY(h, dev_realloc(h->slab, need)); h->slab_cap = need; }
         if (h->n_t > h->tile_cap) { HIP_TRY(h, dev_realloc(h->tile_flag, (size_t)h->n_t)); h->tile_cap = h->n_t; }
         HIP_TRY(h, hipMemsetAsync(h->tile_flag, 0, sizeof(int) * (size_t)h->n_t, h->stream));
@@ -842,7 +842,7 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags) {
     const bool whole = h->i_begin == 0 && h->i_end == h->N;
     const bool tile_shard = n_local > 0 && (h->i_begin % WAVE) == 0 && ((h->i_end % WAVE) == 0 || h->i_end == h->N) && list_cut &&
                             h->n_t < 32768;
-    const bool sym = !h->z3 && !h->rad && (whole || tile_shard) && h->slab && need <= h->slab_cap &&
+    const bool sym = !h->z3 && (whole || tile_shard) && h->slab && need <= h->slab_cap &&
                      h->dpp_dir != 0 && h->prm.enabled[SFM_FORCE_PEDESTRIAN] &&
                      (h->sym_mode == 1 || (h->sym_mode < 0 && h->N >= 256));
     h->used_sym = sym;
@@ -894,9 +894,9 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags) {
                 ++launches;
             }
             if (sa.work) launches += 1;
-            HIP_TRY(h, launch_sym_pair(a, sa, h->stream));
+            HIP_TRY(h, launch_sym_pair(h->rad, a, sa, h->stream));
             if (fork) HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
-            HIP_TRY(h, launch_sym_epilogue(a, sa, h->stream));
+            HIP_TRY(h, launch_sym_epilogue(h->rad, a, sa, h->stream));
             launches += 2;
         } else if (n_local > 0) {
             HIP_TRY(h, launch_tick(ipw, team, h->z3, h->rad, a, h->stream));
@@ -947,7 +947,7 @@ int sfm_profile_dominant_kernel(SfmHandle* h, int reps, float* avg_us) {
         HIP_TRY(h, launch_strip_bounds(a.tile_box, a.tile_vmax, h->n_t, tps, n_strips, h->strip_box, h->strip_vmax, h->stream));
     HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
     for (int r = 0; r < reps; ++r) {
-        if (h->used_sym) HIP_TRY(h, launch_sym_pair(a, sa, h->stream));
+        if (h->used_sym) HIP_TRY(h, launch_sym_pair(h->rad, a, sa, h->stream));
         else if (n_local > 0) HIP_TRY(h, launch_tick(ipw, team, h->z3, h->rad, a, h->stream));
     }
     HIP_TRY(h, hipEventRecord(h->ev1, h->stream));

@@ -1099,8 +1099,9 @@ __global__ void sfm_dpp_probe_kernel(int* out) {       // which way does wave_ro
     out[lane] = __builtin_amdgcn_update_dpp(0, lane, 0x134, 0xf, 0xf, false);
 }
 
-__global__ __launch_bounds__(BLOCK) void sfm_pair_sym_kernel(const float4* __restrict__ pk, const IxConst c,
-                                                             const SymArgs sa) {
+template <bool RAD>
+__global__ __launch_bounds__(BLOCK) void sfm_pair_sym_kernel(const float4* __restrict__ pk, const float* __restrict__ radius,
+                                                             const IxConst c, const SymArgs sa) {
     __shared__ float2 s_fi[WAVES_PER_BLOCK][WAVE];
     __shared__ float2 s_fj[WAVES_PER_BLOCK][WAVE];
     const int tid = threadIdx.x;
@@ -1151,6 +1152,8 @@ __global__ __launch_bounds__(BLOCK) void sfm_pair_sym_kernel(const float4* __res
         const float4 pj = pk[tb * WAVE + lane];
         const int i_loc0 = (lane + sa.dir * sig0) & (WAVE - 1);
         const float4 pi0 = pk[ta * WAVE + i_loc0];
+        float rj = 0.f, ri = 0.f;                    // use_ped_radius: the radii travel with their pedestrians
+        if (RAD) { rj = radius[tb * WAVE + lane]; ri = radius[ta * WAVE + i_loc0]; }
         // lite cutoff (tested while the two loads above are in flight): every term of this tile pair is provably
         // < 2^-40 A -> nothing to do; the epilogue applies the same test and does not read this pair's slab rows
         if (sa.box && !sa.work && shift != 0 &&
@@ -1164,12 +1167,13 @@ __global__ __launch_bounds__(BLOCK) void sfm_pair_sym_kernel(const float4* __res
         float xi = pi0.x, yi = pi0.y, vxi = pi0.z, vyi = pi0.w;
         auto step = [&](bool both) {
             float cx = 0.f, cy = 0.f, cz = 0.f, rinv;
-            moussaid<false, false, false>(c, pj.x - xi, pj.y - yi, 0.f, vxi - pj.z, vyi - pj.w, 0.f, 0.f, cx, cy, cz, rinv);
+            moussaid<false, RAD, false>(c, pj.x - xi, pj.y - yi, 0.f, vxi - pj.z, vyi - pj.w, 0.f, RAD ? ri + rj : 0.f, cx, cy, cz, rinv);
             flag = max(flag, __float_as_int(rinv));
             fxi += cx;
             fyi += cy;
             if (both) { fxj -= cx; fyj -= cy; }
             xi = rot1(xi); yi = rot1(yi); vxi = rot1(vxi); vyi = rot1(vyi);
+            if (RAD) ri = rot1(ri);
             fxi = rot1(fxi); fyi = rot1(fyi);
         };
         // sigma = 32 on a diagonal tile meets every unordered pair {l, l+32} in BOTH lanes: one-sided there
@@ -1348,7 +1352,8 @@ __global__ __launch_bounds__(EPI_BLOCK) void sfm_sym_epilogue_kernel(const TickA
                 const int j = j0 + lane;
                 const float4 pj = a.pk_cur[min(j, N - 1)];
                 float cx = 0.f, cy = 0.f, cz = 0.f, rinv;
-                moussaid<false, false, true>(a.ped, pj.x - xi, pj.y - yi, 0.f, vxi - pj.z, vyi - pj.w, 0.f, 0.f, cx, cy, cz, rinv);
+                moussaid<false, RAD, true>(a.ped, pj.x - xi, pj.y - yi, 0.f, vxi - pj.z, vyi - pj.w, 0.f,
+                                           RAD ? a.radius[ip] + a.radius[min(j, N - 1)] : 0.f, cx, cy, cz, rinv);
                 const bool valid = (j < N) & (j != ip);
                 gx += valid ? cx : 0.f;
                 gy += valid ? cy : 0.f;
@@ -1515,7 +1520,7 @@ hipError_t launch_geometry(bool rad, const TickArgs& a, hipStream_t st) {
     return hipGetLastError();
 }
 
-hipError_t launch_sym_pair(const TickArgs& a, const SymArgs& sa, hipStream_t st) {
+hipError_t launch_sym_pair(bool rad, const TickArgs& a, const SymArgs& sa, hipStream_t st) {
     if (a.N <= 1 || !a.en_ped) return hipSuccess;
     if (sa.work) {
         // cutoff on: compact the tile pairs that have to be evaluated, then a resident grid takes contiguous runs of them
@@ -1534,10 +1539,12 @@ hipError_t launch_sym_pair(const TickArgs& a, const SymArgs& sa, hipStream_t st)
         // a few times more workgroups than fit at once (8 per CU): short runs interleave better with the geometry kernel's
         // workgroups and even out the tail; measured best 4x at 256 tiles, 16x from 1024 tiles on
         const int rounds = std::min(16, std::max(2, sa.n_t / 64));
-        hipLaunchKernelGGL(sfm_pair_sym_kernel, dim3(256 * 8 * rounds), dim3(BLOCK), 0, st, a.pk_cur, a.ped, sa);
+        if (rad) hipLaunchKernelGGL(sfm_pair_sym_kernel<true>, dim3(256 * 8 * rounds), dim3(BLOCK), 0, st, a.pk_cur, a.radius, a.ped, sa);
+        else hipLaunchKernelGGL(sfm_pair_sym_kernel<false>, dim3(256 * 8 * rounds), dim3(BLOCK), 0, st, a.pk_cur, a.radius, a.ped, sa);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(sfm_pair_sym_kernel, dim3(sa.n_t, sa.n_t / 2 + 1), dim3(BLOCK), 0, st, a.pk_cur, a.ped, sa);
+    if (rad) hipLaunchKernelGGL(sfm_pair_sym_kernel<true>, dim3(sa.n_t, sa.n_t / 2 + 1), dim3(BLOCK), 0, st, a.pk_cur, a.radius, a.ped, sa);
+    else hipLaunchKernelGGL(sfm_pair_sym_kernel<false>, dim3(sa.n_t, sa.n_t / 2 + 1), dim3(BLOCK), 0, st, a.pk_cur, a.radius, a.ped, sa);
     return hipGetLastError();
 }
 
@@ -1554,12 +1561,13 @@ hipError_t launch_strip_bounds(const float4* box, const float* vmax, int n_t, in
     return hipGetLastError();
 }
 
-hipError_t launch_sym_epilogue(const TickArgs& a, const SymArgs& sa, hipStream_t st) {
+hipError_t launch_sym_epilogue(bool rad, const TickArgs& a, const SymArgs& sa, hipStream_t st) {
     if (a.N <= 0) return hipSuccess;
     TickArgs b = a;
     b.adv.block0 = sa.t_hi - sa.t_lo;
     const int extra = a.adv.M > 0 ? (a.adv.M + EPI_WAVES - 1) / EPI_WAVES : 0;
-    hipLaunchKernelGGL((sfm_sym_epilogue_kernel<false>), dim3(sa.t_hi - sa.t_lo + extra), dim3(EPI_BLOCK), 0, st, b, sa);
+    if (rad) hipLaunchKernelGGL((sfm_sym_epilogue_kernel<true>), dim3(sa.t_hi - sa.t_lo + extra), dim3(EPI_BLOCK), 0, st, b, sa);
+    else hipLaunchKernelGGL((sfm_sym_epilogue_kernel<false>), dim3(sa.t_hi - sa.t_lo + extra), dim3(EPI_BLOCK), 0, st, b, sa);
     return hipGetLastError();
 }
 

@@ -175,6 +175,8 @@ def test_radius_and_z_variants_vs_oracle(variant, reorder, monkeypatch):
         eng.set_dynamic_obstacles(sc.dynamic_obstacles, sc.dynamic_vel)
         eng.upload_state(sc.loc, sc.vel, sc.waypoint, sc.target_speed, sc.radius, None)
         eng.tick(record=True)
+        # use_ped_radius rides the symmetric kernel (the radii rotate with their pedestrians); a z spread needs the ordered one
+        assert ("sym" in eng.kernel_variant()) == (variant == "radius")
         for name in O.FORCE_NAMES:
             P.check_force(name, eng.forces(name), per[name], diag[name][1], diag[name][0])
         P.check_velocity(eng.velocities(), v_new, diag["total"][0], 0.05)
