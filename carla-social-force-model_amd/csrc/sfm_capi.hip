@@ -815,6 +815,16 @@ static void strip_shape(const SfmHandle* h, int* tps, int* n_strips) {
     *n_strips = on ? (h->n_t + *tps - 1) / *tps : 0;
 }
 
+// the symmetric path's view of one tick: slab, tile-pair list (list cutoff) or boxes (lite cutoff), strips, own tile range
+static SymArgs make_sym_args(const SfmHandle* h, const TickArgs& a, int tps, int n_strips, int debug_steps, unsigned long long* stamps) {
+    const bool lite = a.tile_box_out != nullptr;
+    const bool list = a.tile_box && !lite;
+    return SymArgs{h->slab, h->tile_flag, h->n_t, slab_stride(h->n_t), h->dpp_dir, debug_steps,
+                   list ? h->work : nullptr, list ? h->work_count : nullptr, lite ? a.tile_box : nullptr, lite ? a.tile_vmax : nullptr,
+                   a.cut_scale, a.cut_pad, stamps, h->strip_box, h->strip_vmax, tps, n_strips,
+                   h->i_begin / WAVE, (h->i_end + WAVE - 1) / WAVE};
+}
+
 static int run_ticks(SfmHandle* h, int ticks, uint32_t flags) {
     int rc = bind(h);
     if (rc) return rc;
@@ -828,7 +838,7 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags) {
     h->ipw_last = ipw;
     int tps = 1, n_strips = 0;
     strip_shape(h, &tps, &n_strips);
-    // symmetric path: whole crowd on this handle, planar, no radius; auto mode wants >= 4 tiles
+    // symmetric path: planar crowd, the whole of it on this handle or a tile-aligned shard; auto mode wants >= 4 tiles
     const size_t need = (size_t)h->n_t * (size_t)slab_stride(h->n_t);
     bool order_pays, list_cut;                      // compact tiles only matter to the tile cutoff and the geometry kernel
     {
@@ -861,9 +871,9 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags) {
         ++h->ticks_since_sort;
         TickArgs a;
         fill_args(h, a, flags);
-        // border / obstacle forces only need the tick's input state.  With the symmetric path they run on the
-        // side stream BESIDE the pair kernel (memory-latency-bound next to VALU-bound) and join before the
-        // epilogue; the ordered kernel consumes them itself, so there they simply run first.
+        // border / obstacle forces only need the tick's input state.  With the symmetric path they run on the side
+        // stream beside the list / pair kernels and join before the epilogue (both are VALU-bound, so this buys a head
+        // start rather than an overlap: DESIGN.md 3.4); the ordered kernel consumes them itself, so there they run first.
         if (h->fsm_on && n_local > 0) {           // modes first: target speeds and the border mask feed the forces
             HIP_TRY(h, launch_modes(a, h->stream));
             ++launches;
@@ -885,10 +895,7 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags) {
             ++launches;
         }
         if (sym) {
-            SymArgs sa{h->slab, h->tile_flag, h->n_t, slab_stride(h->n_t), h->dpp_dir, h->debug_steps,
-                       (a.tile_box && !lite) ? h->work : nullptr, (a.tile_box && !lite) ? h->work_count : nullptr,
-                       lite ? a.tile_box : nullptr, lite ? a.tile_vmax : nullptr, a.cut_scale, a.cut_pad, h->stamps,
-                       h->strip_box, h->strip_vmax, tps, n_strips, h->i_begin / WAVE, (h->i_end + WAVE - 1) / WAVE};
+            const SymArgs sa = make_sym_args(h, a, tps, n_strips, h->debug_steps, h->stamps);
             if (sa.work && n_strips > 0) {
                 HIP_TRY(h, launch_strip_bounds(a.tile_box, a.tile_vmax, h->n_t, tps, n_strips, h->strip_box, h->strip_vmax, h->stream));
                 ++launches;
@@ -938,10 +945,7 @@ int sfm_profile_dominant_kernel(SfmHandle* h, int reps, float* avg_us) {
     TickArgs a;
     fill_args(h, a, 0);
     if (h->used_sym) a.geo = nullptr;
-    const bool lite = a.tile_box_out != nullptr;
-    SymArgs sa{h->slab, h->tile_flag, h->n_t, slab_stride(h->n_t), h->dpp_dir, -1, (a.tile_box && !lite) ? h->work : nullptr,
-               (a.tile_box && !lite) ? h->work_count : nullptr, lite ? a.tile_box : nullptr, lite ? a.tile_vmax : nullptr,
-               a.cut_scale, a.cut_pad, nullptr, h->strip_box, h->strip_vmax, tps, n_strips, h->i_begin / WAVE, (h->i_end + WAVE - 1) / WAVE};
+    const SymArgs sa = make_sym_args(h, a, tps, n_strips, -1, nullptr);
     if (a.tile_box) HIP_TRY(h, launch_tile_bounds(a.pk_cur, h->N, const_cast<float4*>(a.tile_box), const_cast<float*>(a.tile_vmax), h->stream));
     if (sa.work && n_strips > 0)
         HIP_TRY(h, launch_strip_bounds(a.tile_box, a.tile_vmax, h->n_t, tps, n_strips, h->strip_box, h->strip_vmax, h->stream));
