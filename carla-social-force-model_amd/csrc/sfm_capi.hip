@@ -33,7 +33,7 @@ hipError_t launch_gather(const uint32_t* src, int N, const float4* pk_in, float4
                          const float4* own_in, float4* own_out, const float* rad_in, float* rad_out, const uint8_t* cr_in,
                          uint8_t* cr_out, const uint32_t* dr_in, uint32_t* dr_out, const uint32_t* id_in, uint32_t* id_out,
                          hipStream_t st);
-hipError_t launch_tile_bounds(const float4* pk, int N, float4* box, float* vmax, hipStream_t st);
+hipError_t launch_tile_bounds(const float4* pk, const float2* zv, int N, float4* box, float* vmax, hipStream_t st);
 int probe_dpp_direction(hipStream_t st);
 hipError_t launch_dynamic_boxes(float4* ctr, const int* off, const float2* local, const float2* rot, float2* pts, int M,
                                 float dt, int advance, hipStream_t st);
@@ -880,7 +880,7 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags) {
         }
         const bool lite = a.tile_box_out != nullptr;
         if (a.tile_box && !(lite && h->boxes_valid)) {   // boxes / speeds of this tick's input state (all tiles)
-            HIP_TRY(h, launch_tile_bounds(a.pk_cur, h->N, const_cast<float4*>(a.tile_box), const_cast<float*>(a.tile_vmax), h->stream));
+            HIP_TRY(h, launch_tile_bounds(a.pk_cur, h->z3 ? a.zv_cur : nullptr, h->N, const_cast<float4*>(a.tile_box), const_cast<float*>(a.tile_vmax), h->stream));
             ++launches;
         }
         const bool fork = a.geo && n_local > 0 && sym && h->overlap_geo;
@@ -946,7 +946,7 @@ int sfm_profile_dominant_kernel(SfmHandle* h, int reps, float* avg_us) {
     fill_args(h, a, 0);
     if (h->used_sym) a.geo = nullptr;
     const SymArgs sa = make_sym_args(h, a, tps, n_strips, -1, nullptr);
-    if (a.tile_box) HIP_TRY(h, launch_tile_bounds(a.pk_cur, h->N, const_cast<float4*>(a.tile_box), const_cast<float*>(a.tile_vmax), h->stream));
+    if (a.tile_box) HIP_TRY(h, launch_tile_bounds(a.pk_cur, h->z3 ? a.zv_cur : nullptr, h->N, const_cast<float4*>(a.tile_box), const_cast<float*>(a.tile_vmax), h->stream));
     if (sa.work && n_strips > 0)
         HIP_TRY(h, launch_strip_bounds(a.tile_box, a.tile_vmax, h->n_t, tps, n_strips, h->strip_box, h->strip_vmax, h->stream));
     HIP_TRY(h, hipEventRecord(h->ev0, h->stream));

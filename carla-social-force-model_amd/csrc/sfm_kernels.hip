@@ -645,14 +645,18 @@ __global__ __launch_bounds__(BLOCK) void sfm_tick_kernel(const TickArgs a) {
         const bool cut = a.tile_box != nullptr && N <= 64 * 64 * WAVE;
         unsigned int keep_lo = 0xffffffffu, keep_hi = 0xffffffffu;
         if (cut) {
-            const int n_t = (N + WAVE - 1) / WAVE, ti = min(ibase, a.i_end - 1) >> 6;
-            const float4 bt = a.tile_box[ti];
-            const float vt = a.tile_vmax[ti];
+            // the wave's rows lie in one 64-tile when the shard starts on a multiple of IPW; a ragged shard start can put
+            // them in two, and then a partner tile is kept if it is not negligible for either
+            const int n_t = (N + WAVE - 1) / WAVE, ti = min(ibase, a.i_end - 1) >> 6, ti2 = min(ibase + IPW - 1, a.i_end - 1) >> 6;
+            const float4 bt = a.tile_box[ti], bt2 = a.tile_box[ti2];
+            const float vt = a.tile_vmax[ti], vt2 = a.tile_vmax[ti2];
             unsigned long long km = 0ull;
             for (int t = 0; t * WAVE < n_t; ++t) {
                 const int u = t * WAVE + lane;
-                const bool keep = (u < n_t) && !tiles_negligible(bt, vt, a.tile_box[min(u, n_t - 1)], a.tile_vmax[min(u, n_t - 1)],
-                                                                 a.ped.lam, a.cut_scale, a.cut_pad);
+                const float4 bu = a.tile_box[min(u, n_t - 1)];
+                const float vu = a.tile_vmax[min(u, n_t - 1)];
+                bool keep = (u < n_t) && !tiles_negligible(bt, vt, bu, vu, a.ped.lam, a.cut_scale, a.cut_pad);
+                if (ti2 != ti) keep |= (u < n_t) && !tiles_negligible(bt2, vt2, bu, vu, a.ped.lam, a.cut_scale, a.cut_pad);   // uniform
                 km |= (unsigned long long)keep << t;
             }
             keep_lo = (unsigned int)km;
@@ -920,8 +924,8 @@ __global__ __launch_bounds__(BLOCK) void sfm_tick_kernel(const TickArgs a) {
     }
 }
 
-__global__ __launch_bounds__(WAVE) void sfm_tile_bounds_kernel(const float4* __restrict__ pk, int N, float4* __restrict__ box,
-                                                               float* __restrict__ vmax) {
+__global__ __launch_bounds__(WAVE) void sfm_tile_bounds_kernel(const float4* __restrict__ pk, const float2* __restrict__ zv, int N,
+                                                               float4* __restrict__ box, float* __restrict__ vmax) {
     const int t = blockIdx.x, lane = threadIdx.x;
     const int i = t * WAVE + lane;
     const float inf = __builtin_inff();
@@ -930,7 +934,8 @@ __global__ __launch_bounds__(WAVE) void sfm_tile_bounds_kernel(const float4* __r
         const float4 s = pk[i];
         if (fabsf(s.x) < 1.0e14f) {                             // despawned pedestrians are parked far away: not in the box
             x0 = x1 = s.x; y0 = y1 = s.y;
-            v = sqrtf(fmaf(s.z, s.z, s.w * s.w)) * 1.000001f;  // rounded up: the bound must stay a bound
+            const float vz = zv ? zv[i].y : 0.0f;               // 3-D crowds: |D| is a 3-component norm (forces.py:85-86), so is the speed
+            v = sqrtf(fmaf(s.z, s.z, fmaf(s.w, s.w, vz * vz))) * 1.000001f;  // rounded up: the bound must stay a bound
         }
     }
 #pragma unroll
@@ -1128,7 +1133,7 @@ __global__ __launch_bounds__(BLOCK) void sfm_pair_sym_kernel(const float4* __res
     bool diag = false;
     if (shift == 0) {
         // diagonal tiles are half the work (32 steps): two of them share a workgroup, two waves each
-        if (bx - sa.t_lo >= half_up) return;          // (never in the list)
+        if (!sa.work && bx - sa.t_lo >= half_up) return;   // grid mode only (the list holds each diagonal item once)
         ta = (wave < 2) ? bx : bx + half_up;
         if (ta >= sa.t_hi) { ta = -1; }
         tb = ta;
@@ -1136,7 +1141,10 @@ __global__ __launch_bounds__(BLOCK) void sfm_pair_sym_kernel(const float4* __res
         sig0 = 1 + 16 * (wave & 1);               // sigma 1..16 / 17..32 (sigma = 32 is one-sided)
         nsteps = 16;
     } else {
-        if (!(n_t & 1) && shift == (n_t >> 1) && bx >= (n_t >> 1)) return;   // antipodal pairs appear twice
+        // Antipodal pairs (even n_t, shift n_t/2) appear twice in the 2-D grid: the upper half leaves.  The list
+        // builders have already dropped that duplicate for own-own pairs, and a ONE-SIDED antipodal item (partner tile
+        // on another rank) must be evaluated by whichever own tile it names -- so this is grid mode only.
+        if (!sa.work && !(n_t & 1) && shift == (n_t >> 1) && bx >= (n_t >> 1)) return;
         ta = bx;
         tb = bx + shift;
         if (tb >= n_t) tb -= n_t;
@@ -1548,9 +1556,9 @@ hipError_t launch_sym_pair(bool rad, const TickArgs& a, const SymArgs& sa, hipSt
     return hipGetLastError();
 }
 
-hipError_t launch_tile_bounds(const float4* pk, int N, float4* box, float* vmax, hipStream_t st) {
+hipError_t launch_tile_bounds(const float4* pk, const float2* zv, int N, float4* box, float* vmax, hipStream_t st) {
     if (N <= 0) return hipSuccess;
-    hipLaunchKernelGGL(sfm_tile_bounds_kernel, dim3((N + WAVE - 1) / WAVE), dim3(WAVE), 0, st, pk, N, box, vmax);
+    hipLaunchKernelGGL(sfm_tile_bounds_kernel, dim3((N + WAVE - 1) / WAVE), dim3(WAVE), 0, st, pk, zv, N, box, vmax);
     return hipGetLastError();
 }
 

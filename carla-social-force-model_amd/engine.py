@@ -275,8 +275,8 @@ class SfmEngine:
         a = {k: np.full(n, np.nan, np.float32) for k in ("x", "y", "z", "vx", "vy", "vz", "wx", "wy")}
         self._check(self._lib.sfm_download_state(self._h, *(fptr(a[k]) for k in ("x", "y", "z", "vx", "vy", "vz", "wx", "wy"))),
                     "sfm_download_state")
-        if self.planar:
-            a["z"][self.shard[0]:self.shard[1]] = np.float32(self._z0)
+        if self.planar:      # rows are in the library's own order: the owned pedestrians are the ones a value came back for
+            a["z"][~np.isnan(a["x"])] = np.float32(self._z0)
         loc = np.stack([a["x"], a["y"], a["z"]], axis=1).astype(np.float64)
         vel = np.stack([a["vx"], a["vy"], a["vz"]], axis=1).astype(np.float64)
         wp = np.stack([a["wx"], a["wy"]], axis=1).astype(np.float64)

@@ -14,7 +14,9 @@ pedestrian_state, forces -- and executes *their* code on seeded inputs:
 pedestrian_simulation.py itself is not imported (it pulls check_traffic -> shapely, absent in this image);
 the three glue lines above call the reference functions it calls, in its order.
 
-Usage:  python tests/golden/make_golden.py            (rewrites every fixture)
+Usage:  python tests/golden/make_golden.py                      (rewrites every fixture)
+        python tests/golden/make_golden.py --out DIR NAME ...   (only the named cases, into DIR: what
+                                                                 tests/test_golden_regen.py does to catch generator drift)
 """
 import copy
 import os
@@ -107,7 +109,13 @@ def ref_tick(peds, fd):
     return per, total, v_new
 
 
+OUT_DIR = HERE
+ONLY = None            # None = every case; otherwise the set of case names to (re)generate
+
+
 def make_case(name, sc, cfg, trajectory=True):
+    if ONLY is not None and name not in ONLY:
+        return
     out = gio.encode_inputs(sc, cfg, DT)
     with np.errstate(all="ignore"):
         peds = build_ref_state(sc, cfg)
@@ -143,7 +151,7 @@ def make_case(name, sc, cfg, trajectory=True):
         out["ref_traj_loc"] = np.array(locs)
         out["ref_traj_vel"] = np.array(vels)
         out["ref_traj_wp"] = np.array(wps)
-    path = os.path.join(HERE, name + ".npz")
+    path = os.path.join(OUT_DIR, name + ".npz")
     np.savez_compressed(path, **out)
     print(f"  {name}: N={sc.n} forces={list(per)} -> {os.path.getsize(path)//1024} KiB")
 
@@ -217,4 +225,8 @@ def main():
 
 
 if __name__ == "__main__":
+    argv = sys.argv[1:]
+    if argv and argv[0] == "--out":
+        OUT_DIR = argv[1]
+        ONLY = set(argv[2:]) or None
     main()

@@ -209,3 +209,39 @@ def test_two_processes_share_the_gpu_and_match_the_single_process_run(tmp_path, 
     eng.close()
     assert np.allclose(z["loc"], loc, rtol=2e-5, atol=2e-5) and np.allclose(z["vel"], vel, rtol=2e-5, atol=2e-5)
     assert np.array_equal(z["wp"], wp)
+
+
+def test_antipodal_tile_pairs_across_the_shard_boundary_are_evaluated(monkeypatch):
+    """Even tile count, two shards, a crowd narrower than the cutoff reach: the pair (tile t, tile t + n_t/2) has its two
+    tiles on different ranks and is NOT negligible, so each rank must evaluate its own side of it (a one-sided list item).
+    Round 1 dropped those items for the upper-half tiles (and with them the rest of the workgroup's run of the list)."""
+    import torch
+    from carla_social_force_model_amd.stepper import HipShardEngine, shard_bounds
+    for k, v in {"SFM_CUTOFF": "1", "SFM_SYM": "1", "SFM_RESORT_EVERY": "0"}.items():
+        monkeypatch.setenv(k, v)
+    cfg = default_sfm_config(("acceleration_force", "pedestrian_force"))
+    sc = scenarios.make_scenario(8192, 424242, density=1.0)           # 90 m square, 128 tiles
+    whole = HipShardEngine(cfg, 0.05)
+    whole.load(sc)
+    whole.run(1)
+    ref = whole.engine.state()
+    assert "sym" in whole.engine.kernel_variant()
+    whole.close()
+    got = []
+    for r in range(2):
+        e = HipShardEngine(cfg, 0.05)
+        n, n_pad = e.load(sc)
+        lo, hi, _ = shard_bounds(n, n_pad, r, 2)
+        e.set_shard(lo, hi)
+        e.run(1)
+        e.synchronize()
+        assert "sym" in e.engine.kernel_variant()
+        got.append(e.engine.state())
+        e.close()
+    torch.cuda.synchronize()
+    for k in range(2):                                                  # loc, vel
+        mine0, mine1 = ~np.isnan(got[0][k][:, 0]), ~np.isnan(got[1][k][:, 0])
+        assert (mine0 ^ mine1).all()
+        merged = np.where(mine0[:, None], got[0][k], got[1][k])
+        assert np.isfinite(merged).all()
+        assert np.allclose(merged, ref[k], rtol=2e-5, atol=2e-5)
