@@ -8,19 +8,34 @@ A "step" is one SFM tick (one pass of the hot path over the whole crowd): forces
 position update -> arrival / next waypoint, all on the device, state resident in HBM before the timed region.
 Metric: SFM ticks/s (BASELINE.json "SFM ticks/s and ns/pedestrian-pair"); ns/pair is reported beside it.
 
-Workloads (--workload overrides the default):
+Timing protocol.  After W untimed warm-up steps a WINDOW is exactly K steps bracketed by a
+barrier + torch.cuda.synchronize() on both sides, its duration the MAX over ranks.  At least 5 windows are run, and
+more until they add up to >= 1 s (--min-seconds); `value` = K / the MEDIAN window; `windows`, `min`, `max` and the
+mean over all windows are on the line.  `steps` / `warmup` echo the arguments.
+
+Workloads (--workload overrides the default, and the SAME workload can be run at every G):
   G = 1  -> c2: N = 4 096, pedestrian_force + acceleration_force        (the config the metric is quoted on)
   G > 1  -> c5: N = 262 144 + 2 000 borders + 256 static + 512 dynamic obstacles, all forces, STRONG scaling:
-            pedestrians sharded by row (whole 64-row tiles of a spatial packing), one RCCL all-gather of the packed
-            state per tick, plus a gather of the waypoint arrays and an identical re-pack on every rank each 64 ticks.
-            Rank 0 also times 40 ticks of the SAME workload on one GPU before the run ("single_gpu_same_workload")
-            so the strong-scaling speed-up can be read off one line.
+            pedestrians sharded by row (whole 64-row tiles of a spatial packing, shard sizes balanced by pair work),
+            one RCCL all-gather of the packed state per tick, plus a gather of the waypoint arrays and an identical
+            re-pack on every rank each 64 ticks.  Rank 0 first times the SAME workload on ONE GPU with the same
+            protocol ("single_gpu_same_workload"), so the strong-scaling speed-up is on the line;
+            `--gpus 1 --workload c5` prints that N = 1 point as a line of its own.
   SFM_BENCH_REHEARSAL=1 (development only): every rank on cuda:0, collectives over gloo -- runs the multi-rank flow end to
             end on a one-GPU box; its timings mean nothing.
+
+Roofline record.  The dominant kernel is the pedestrian-pair kernel.  Its binding resource is VALU issue (DESIGN.md
+3.6): `roofline.bound = "valu_issue"`, achieved = VALU wave-instructions per launch (SQ_INSTS_VALU, mean per launch from
+the rocprofv3 --pmc passes summarised in profiles/r02_pmc_summary.csv, a tracked file) / the kernel's own launch
+duration measured live with HIP events on the launch stream, against 1024 SIMDs x 0.5 wave-instr/clk x 2.4 GHz.
+`roofline.hbm_algorithmic` keeps SURVEY.md 8d's yardstick (16 B per ordered pair / launch time against 8 TB/s) and
+`roofline.traffic` the HBM bytes per launch from the FETCH_SIZE / WRITE_SIZE passes (same file).
 """
 import argparse
+import csv
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -30,10 +45,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak
+SIMDS, CLOCK_HZ = 1024, 2.4e9
+VALU_PEAK_GINSTR = SIMDS * 0.5 * CLOCK_HZ / 1e9     # v_fma_f32 (wave64): 2 cycles per SIMD (MI355X_MICROARCH.md, cycle constants)
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc_summary.csv")
 
 
 def algorithmic_bytes(sc, forces, n_local, sample=2048, seed=0):
-    """Algorithmic bytes of one launch over n_local pedestrian rows:
+    """Algorithmic bytes of one tick over n_local pedestrian rows:
     16 B per ordered pair (the {x,y,vx,vy} operand stream) + 44 B per own row (28 read + 16 written)
     + 12 B per (pedestrian, border) cull test + 8 B per scanned border point
     + 8 B / 16 B per (pedestrian, static / dynamic obstacle) cull test + 8 B per scanned ring point.
@@ -71,9 +89,11 @@ def algorithmic_bytes(sc, forces, n_local, sample=2048, seed=0):
 
 
 def cpu_baseline(sc, forces, cfg, budget_s=15.0):
-    """The oracle's C/OpenMP port timed on this node's host cores, on a bounded sample of the workload:
-    whole ticks when one fits the budget, otherwise a contiguous block of pedestrian rows of ONE tick
-    (all j are still visited) scaled to a full tick."""
+    """Two CPU legs timed on this node's host cores, on bounded samples of the workload:
+      * the oracle's C/OpenMP float64 port on all cores: whole ticks when one fits the budget, otherwise a contiguous
+        block of pedestrian rows of ONE tick (all j are still visited) scaled to a full tick;
+      * the oracle's NumPy float64 restatement with DENSE (N, N, 3) temporaries on one core -- algorithm-equivalent to the
+        reference's forces.py / stateutils.py (which cannot travel to this box) -- on the first min(N, 2048) pedestrians."""
     from oracle import c_oracle
     from oracle import sfm_oracle as O
     prm = O.OracleParams.from_config(cfg)
@@ -101,8 +121,61 @@ def cpu_baseline(sc, forces, cfg, budget_s=15.0):
         c_oracle.tick(*args, rows=(0, rows), nthreads=cores)
         dt = (time.perf_counter() - t0) * sc.n / rows
         sample = f"rows 0..{rows} of one tick at N={sc.n} (all j visited), scaled to a full tick"
-    return {"value": 1.0 / dt, "unit": "ticks/s", "cores": cores, "kind": "port",
-            "sample": sample + "; oracle/sfm_oracle.c, float64, OpenMP", "ns_per_pair": dt * 1e9 / (sc.n * (sc.n - 1.0))}
+    out = {"value": 1.0 / dt, "unit": "ticks/s", "cores": cores, "kind": "port",
+           "sample": sample + "; oracle/sfm_oracle.c, float64, OpenMP", "ns_per_pair": dt * 1e9 / (sc.n * (sc.n - 1.0))}
+    # NumPy float64, dense temporaries, one core: the reference's own algorithm shape
+    m = min(sc.n, 2048)
+    sub = np.arange(m)
+    try:
+        import threadpoolctl
+        limiter = threadpoolctl.threadpool_limits(1)
+    except Exception:                                                # pragma: no cover
+        limiter = None
+    with np.errstate(all="ignore"):
+        reps, t0 = 0, time.perf_counter()
+        while reps == 0 or (time.perf_counter() - t0 < min(budget_s, 6.0) and reps < 5):
+            f = np.zeros((m, 3))
+            if "acceleration_force" in forces:
+                f = f + O.acceleration_force(sc.loc[sub], sc.vel[sub], sc.waypoint[sub], sc.target_speed[sub], prm.tau)
+            if "pedestrian_force" in forces:
+                f = f + O.pedestrian_force(sc.loc[sub], sc.vel[sub], sc.radius[sub], prm.ped, prm.use_ped_radius, chunk=m,
+                                           diagnostics=False)[0]
+            O.new_velocities(sc.vel[sub], f, sc.target_speed[sub], 0.05)
+            reps += 1
+        dn = (time.perf_counter() - t0) / reps
+    if limiter is not None:
+        limiter.unset()
+    out["numpy_dense_1core"] = {"value": 1.0 / dn, "unit": "ticks/s", "cores": 1, "kind": "port", "n_pedestrians": m,
+                                "ns_per_pair": dn * 1e9 / (m * (m - 1.0)),
+                                "sample": f"{reps} ticks of acceleration + pedestrian force + cap on the first {m} pedestrians; "
+                                          "oracle/sfm_oracle.py, float64, dense (N,N,3) temporaries like forces.py:74-117"}
+    return out
+
+
+def pmc_counters(workload, kernel):
+    """Mean per-launch counter values of `kernel` on `workload` from the tracked PMC summary (tools/pmc_summarize.py)."""
+    out = {}
+    try:
+        with open(PMC_SUMMARY) as f:
+            for row in csv.DictReader(f):
+                if row["workload"] == workload and row["kernel"] == kernel:
+                    out[row["counter"]] = float(row["mean_per_launch"])
+    except OSError:
+        pass
+    return out
+
+
+def timed_windows(step, barrier, reduce_max, steps, min_windows, min_seconds, max_windows=5000):
+    """Windows of exactly `steps` steps, each bracketed by barrier() on both sides; stops after >= min_windows windows
+    adding up to >= min_seconds.  reduce_max makes the duration (and therefore the stop decision) identical on every rank."""
+    times = []
+    while len(times) < min_windows or (sum(times) < min_seconds and len(times) < max_windows):
+        barrier()
+        t0 = time.perf_counter()
+        step(steps)
+        barrier()
+        times.append(reduce_max(time.perf_counter() - t0))
+    return times
 
 
 def main():
@@ -111,7 +184,10 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--workload", default="auto", choices=["auto", "c1", "c2", "c3", "c4", "c5"])
+    ap.add_argument("--windows", type=int, default=5, help="minimum number of timed windows of --steps steps")
+    ap.add_argument("--min-seconds", type=float, default=1.0, help="keep adding windows until they total this long")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-single-ref", action="store_true", help="G > 1: skip the one-GPU run of the same workload")
     ap.add_argument("--cpu-budget", type=float, default=10.0)
     args = ap.parse_args()
 
@@ -145,17 +221,19 @@ def main():
     cfg = default_sfm_config(forces)
     dt = 0.05
 
+    def local_barrier():
+        torch.cuda.synchronize()
+
     single_ref = None
-    if world > 1 and rank == 0:
-        # the same workload on ONE GPU, a few ticks, so the strong-scaling speed-up is on this line
+    if world > 1 and rank == 0 and not args.no_single_ref:
+        # the same workload on ONE GPU, same protocol (K-step windows incl. the periodic re-pack), so the strong-scaling
+        # speed-up is on this line
         e1 = HipShardEngine(cfg, dt, device=local)
         s1 = ShardedStepper(e1, sc)
-        s1.step(10)
-        e1.synchronize()
-        t0 = time.perf_counter()
-        s1.step(40)
-        e1.synchronize()
-        single_ref = 40.0 / (time.perf_counter() - t0)
+        s1.step(args.warmup)
+        t1 = timed_windows(s1.step, local_barrier, lambda v: v, args.steps, max(3, args.windows), args.min_seconds)
+        single_ref = {"value": args.steps / statistics.median(t1), "unit": "ticks/s", "windows": len(t1),
+                      "min": args.steps / max(t1), "max": args.steps / min(t1)}
         e1.close()
 
     eng = HipShardEngine(cfg, dt, device=local)
@@ -167,76 +245,94 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def reduce_max(v):
+        if world == 1:
+            return v
+        t = torch.tensor([v], dtype=torch.float64, device="cpu" if rehearsal else f"cuda:{local}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     st.exchange()                 # brings the communicator up outside the timed region (idempotent on a fresh state)
     st.step(args.warmup)
-    barrier()
-    t0 = time.perf_counter()
-    st.step(args.steps)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local}")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    times = timed_windows(st.step, barrier, reduce_max, args.steps, args.windows, args.min_seconds)
+    elapsed = statistics.median(times)
 
     # whole tick on the launch stream (HIP events, no collective in between) ...
     reps = min(max(args.steps, 1), 200 if sc.n <= 16384 else 10)
     eng.engine.run(reps, redraw=True)
     ev_ms, ev_ticks, ev_launches = eng.engine.timing()
     tick_us = ev_ms * 1e3 / max(ev_ticks, 1)
-    # ... and the dominant kernel (the pedestrian-pair kernel) on its own, same stream, HIP events
-    kernel_us = eng.engine.profile_dominant_kernel(reps)
     variant = eng.engine.kernel_variant()
-    dominant = "sfm_pair_sym_kernel" if "sym" in variant else variant
+    sym = "sym" in variant
+    pair_items = pair_terms = None
+    if sym and "pedestrian_force" in forces:
+        pair_items, pair_terms = eng.engine.pair_work()             # of the last tick above
+    # ... and the dominant kernel (the pedestrian-pair kernel) ALONE, same stream, HIP events (the tile-pair list of the
+    # cutoff configs is built once, outside the timed launches)
+    kernel_us = eng.engine.profile_dominant_kernel(reps)
+    dominant = "sfm_pair_sym_kernel" if sym else "sfm_tick_kernel"
     alg = 16.0 * (hi - lo) * (sc.n - 1.0) if "pedestrian_force" in forces else 0.0
-    if "sym" not in variant:
+    if not sym:
         alg += 44.0 * (hi - lo)                      # the ordered kernel also reads / writes the own rows
     alg_tick = algorithmic_bytes(sc, forces, hi - lo)
-    achieved = alg / (kernel_us * 1e-6) / 1e9
+    alg_gbs = alg / (kernel_us * 1e-6) / 1e9
+    # counters of this kernel on this workload (whole crowd on one GPU), mean per launch, from the tracked summary
+    pmc = pmc_counters(name, dominant) if world == 1 else {}
     traffic = None
-    try:                                              # HBM-side bytes per launch from the committed PMC passes
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-            traffic = json.load(f).get(name, {}).get(dominant, {}).get("hbm_bytes")
-    except (OSError, ValueError):
-        pass
-    # The binding resource of the pair kernel is VALU issue, not HBM: price it too.  One systolic
-    # step of a wave = 64 pairs = 47 plain + 6 DPP + 2 v_bfi + v_cmp/v_cndmask + 5 transcendental ops; with the issue
-    # costs measured on MI355X (tools/valu_microbench.hip: 2.2 / 4.4 / 4.4 / 8.7 / 9.3 cycles) that is ~200 cycles.
-    valu = None
-    if "sym" in variant and "pedestrian_force" in forces and world == 1 and sc.n < 8192:      # no tile cutoff: every pair is evaluated
-        n_t = (sc.n + 63) // 64
-        wave_steps = 64.0 * n_t * (n_t - 1) / 2 + 32.0 * n_t
-        simds, clock_hz, model = 1024, 2.4e9, 200.0
-        spent = kernel_us * 1e-6 * clock_hz * simds / wave_steps
-        valu = {"bound": "valu_issue", "model_cycles_per_wave_step": model, "achieved_cycles_per_wave_step": spent,
-                "frac": model / spent, "wave_steps_per_launch": wave_steps, "simds": simds, "clock_hz": clock_hz,
-                "note": "cycles at the 2.4 GHz peak engine clock (the in-kernel clock read 2.08 GHz under this load: frac ~0.75 at that clock)"}
+    if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:   # KiB; FETCH_SIZE doubled for 16-B/lane reads on gfx950 (MI355X_MICROARCH.md, HBM)
+        traffic = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
+    hbm_alg = {"bound": "hbm", "achieved": alg_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_gbs / HBM_PEAK_GBS,
+               "algorithmic_bytes_per_launch": alg, "traffic_over_algorithmic": (traffic / alg) if (traffic and alg) else None,
+               "note": "SURVEY.md 8d yardstick: 16 B per ORDERED pair x the pairs one launch covers / its launch time. The operand "
+                       "stream is served from registers / L2, so this exceeds the HBM peak as soon as the kernel is fast: it does "
+                       "not bind (traffic_over_algorithmic says how little of it reaches HBM)"}
+    if "SQ_INSTS_VALU" in pmc:
+        insts = pmc["SQ_INSTS_VALU"]
+        ach = insts / (kernel_us * 1e-6) / 1e9
+        roof = {"bound": "valu_issue", "achieved": ach, "peak": VALU_PEAK_GINSTR, "unit": "G wave-instr/s",
+                "frac": ach / VALU_PEAK_GINSTR, "traffic": traffic,
+                "valu_wave_instructions_per_launch": insts,
+                "counters": {k: pmc[k] for k in sorted(pmc)}, "counters_source": "profiles/r02_pmc_summary.csv",
+                "peak_definition": "1024 SIMDs x 0.5 wave64 VALU instr/clk (v_fma_f32 = 2 cycles) x 2.4 GHz"}
+        if pair_terms:
+            roof["valu_instructions_per_64_pair_step"] = insts / (pair_terms / 64.0)
+        if "SQ_WAIT_INST_ANY" in pmc and "SQ_WAVE_CYCLES" in pmc and pmc["SQ_WAVE_CYCLES"] > 0:
+            roof["wait_inst_any_over_wave_cycles"] = pmc["SQ_WAIT_INST_ANY"] / pmc["SQ_WAVE_CYCLES"]
+    else:                                              # no counter pass committed for this workload / rank layout
+        roof = dict(hbm_alg)
+        roof["traffic"] = traffic
+        roof["note"] = "no PMC summary for this workload in profiles/r02_pmc_summary.csv: only the algorithmic-bytes yardstick; " + roof["note"]
+    roof.update({"kernel": dominant, "kernel_variant": variant, "kernel_us": kernel_us, "tick_us": tick_us,
+                 "launches_per_tick": ev_launches / max(ev_ticks, 1), "algorithmic_bytes_per_tick": alg_tick})
+    if roof.get("bound") == "valu_issue":
+        roof["hbm_algorithmic"] = hbm_alg
     barrier()
 
     if rank == 0:
         n = sc.n
         ticks_s = args.steps / elapsed
+        total_t = sum(times)
         out = {
             "metric": "sfm_ticks_per_s", "value": ticks_s, "unit": "ticks/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "windows": len(times), "min": args.steps / max(times), "max": args.steps / min(times),
+            "mean_over_windows": args.steps * len(times) / total_t, "timed_seconds": total_t,
             "config": {"workload": f"{name}: N={n} pedestrians, forces={'+'.join(f.replace('_force', '') for f in forces)}, "
                                    f"borders={len(sc.borders)}, static={len(sc.static_obstacles)}, dynamic={len(sc.dynamic_obstacles)}, "
-                                   f"dt={dt}", "n_pedestrians": n, "sharding": f"rows/{world}" + (", 1 all-gather/tick" if world > 1 else ""),
+                                   f"dt={dt}", "n_pedestrians": n,
+                       "sharding": (f"rows/{world}, tile-aligned, balanced by pair work, 1 all-gather/tick" if world > 1 else "none"),
                        "kernel": variant},
             "ns_per_pair": elapsed / args.steps * 1e9 / (n * (n - 1.0)),
             "pairs_per_s": n * (n - 1.0) * ticks_s,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": dominant, "kernel_us": kernel_us, "algorithmic_bytes_per_launch": alg,
-                         "tick_us": tick_us, "launches_per_tick": ev_launches / max(ev_ticks, 1),
-                         "algorithmic_bytes_per_tick": alg_tick,
-                         "note": "dominant kernel = the pedestrian-pair kernel: 16 B per ordered pair x the pairs one launch "
-                                 "covers / its HIP-event time; traffic = HBM bytes per launch from rocprofv3 PMC passes "
-                                 "(profiles/). The operand stream is served on-chip; the binding resource is VALU issue (DESIGN.md 3.4)"},
+            "roofline": roof,
         }
-        if valu is not None:
-            out["roofline"]["valu_issue"] = valu
+        if pair_terms:
+            # the provably-negligible tile pairs are not evaluated: what the pair kernel actually did
+            out["evaluated_pair_terms_per_tick"] = pair_terms
+            out["evaluated_tile_pair_items_per_tick"] = pair_items
+            out["evaluated_fraction_of_unordered_pairs"] = pair_terms / (n * (n - 1.0) / 2.0) if world == 1 else None
+            out["ns_per_evaluated_pair_term"] = kernel_us * 1e3 / pair_terms
         if "pedestrian_force" in forces:
             # SURVEY.md section 8d, "algorithmic flops": ~65 fp32 VALU ops per ORDERED pedestrian pair against the
             # 7.9e13 lane-ops/s of the chip (256 CUs x 4 SIMDs x 32 lanes/clk x 2.4 GHz); the symmetric kernel evaluates an
@@ -245,7 +341,8 @@ def main():
             out["roofline"]["valu_algorithmic"] = {"ops_per_ordered_pair": 65.0, "achieved_ops_per_s": ops, "peak_ops_per_s": 7.9e13,
                                                    "frac": ops / 7.9e13 / world}
         if single_ref is not None:
-            out["single_gpu_same_workload"] = {"value": single_ref, "unit": "ticks/s", "speedup": ticks_s / single_ref}
+            single_ref["speedup"] = ticks_s / single_ref["value"]
+            out["single_gpu_same_workload"] = single_ref
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sc, forces, cfg, args.cpu_budget)
         print(json.dumps(out), flush=True)

@@ -79,6 +79,7 @@ SYMBOLS = {
     "sfm_get_timing": (C.c_int, [_H, C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "sfm_profile_dominant_kernel": (C.c_int, [_H, C.c_int, C.POINTER(C.c_float)]),
     "sfm_kernel_variant": (C.c_char_p, [_H]),
+    "sfm_get_pair_work": (C.c_int, [_H, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
 }
 
 _lib = None

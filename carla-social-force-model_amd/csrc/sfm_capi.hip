@@ -17,6 +17,7 @@
 namespace sfm {
 hipError_t launch_tick(int ipw, int team, bool z3, bool rad, const TickArgs& a, hipStream_t st);
 hipError_t launch_arrived(const float4* pk, const float4* own, int N, float thr2, uint8_t* mask, hipStream_t st);
+hipError_t launch_sym_list(const TickArgs& a, const SymArgs& sa, hipStream_t st);
 hipError_t launch_sym_pair(bool rad, const TickArgs& a, const SymArgs& sa, hipStream_t st);
 hipError_t launch_sym_epilogue(bool rad, const TickArgs& a, const SymArgs& sa, hipStream_t st);
 hipError_t launch_strip_bounds(const float4* box, const float* vmax, int n_t, int tps, int n_strips, float4* sbox, float* svmax,
@@ -129,6 +130,7 @@ struct SfmHandle {
     bool perm_stale = false;
     float r_max = 0.f;
     bool used_sym = false;
+    bool last_list = false;                // the last symmetric tick ran from the tile-pair list (cutoff on)
 
     uint32_t seed = 0;
     float world_side = 0.f, arrive_thr = 2.0f;
@@ -896,11 +898,15 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags) {
         }
         if (sym) {
             const SymArgs sa = make_sym_args(h, a, tps, n_strips, h->debug_steps, h->stamps);
+            h->last_list = sa.work != nullptr;
             if (sa.work && n_strips > 0) {
                 HIP_TRY(h, launch_strip_bounds(a.tile_box, a.tile_vmax, h->n_t, tps, n_strips, h->strip_box, h->strip_vmax, h->stream));
                 ++launches;
             }
-            if (sa.work) launches += 1;
+            if (sa.work) {
+                HIP_TRY(h, launch_sym_list(a, sa, h->stream));
+                ++launches;
+            }
             HIP_TRY(h, launch_sym_pair(h->rad, a, sa, h->stream));
             if (fork) HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
             HIP_TRY(h, launch_sym_epilogue(h->rad, a, sa, h->stream));
@@ -949,6 +955,7 @@ int sfm_profile_dominant_kernel(SfmHandle* h, int reps, float* avg_us) {
     if (a.tile_box) HIP_TRY(h, launch_tile_bounds(a.pk_cur, h->z3 ? a.zv_cur : nullptr, h->N, const_cast<float4*>(a.tile_box), const_cast<float*>(a.tile_vmax), h->stream));
     if (sa.work && n_strips > 0)
         HIP_TRY(h, launch_strip_bounds(a.tile_box, a.tile_vmax, h->n_t, tps, n_strips, h->strip_box, h->strip_vmax, h->stream));
+    if (h->used_sym) HIP_TRY(h, launch_sym_list(a, sa, h->stream));      // the list is built once, outside the timed launches
     HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
     for (int r = 0; r < reps; ++r) {
         if (h->used_sym) HIP_TRY(h, launch_sym_pair(h->rad, a, sa, h->stream));
@@ -1178,5 +1185,27 @@ int sfm_get_timing(SfmHandle* h, float* elapsed_ms, int* ticks, int* launches) {
 }
 
 const char* sfm_kernel_variant(const SfmHandle* h) { return h ? h->variant : "none"; }
+
+int sfm_get_pair_work(SfmHandle* h, long long* tile_pair_items, long long* pair_terms) {
+    int rc = bind(h);
+    if (rc) return rc;
+    if (!h->pk[0]) return fail(h, SFM_ERR_STATE, "sfm_upload_state has not been called");
+    if (!h->used_sym) return fail(h, SFM_ERR_STATE, "the last tick did not run the symmetric pair kernel");
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const long long t_own = (h->i_end + WAVE - 1) / WAVE - h->i_begin / WAVE;
+    long long items, diag_items = (t_own + 1) / 2;
+    if (h->last_list) {
+        int cnt = 0;
+        HIP_TRY(h, hipMemcpy(&cnt, h->work_count, sizeof(int), hipMemcpyDeviceToHost));
+        items = cnt;
+    } else {                                       // 2-D grid: every unordered tile pair once + the diagonal items
+        const long long n_t = h->n_t;
+        items = n_t * (n_t - 1) / 2 + diag_items;
+    }
+    if (tile_pair_items) *tile_pair_items = items;
+    // a tile-pair item meets 64 x 64 pairs; a diagonal item holds two diagonal tiles of 64 x 32 evaluations each
+    if (pair_terms) *pair_terms = (items - diag_items) * (long long)(WAVE * WAVE) + t_own * (long long)(WAVE * WAVE / 2);
+    return SFM_OK;
+}
 
 }  // extern "C"

@@ -1528,24 +1528,28 @@ hipError_t launch_geometry(bool rad, const TickArgs& a, hipStream_t st) {
     return hipGetLastError();
 }
 
-hipError_t launch_sym_pair(bool rad, const TickArgs& a, const SymArgs& sa, hipStream_t st) {
-    if (a.N <= 1 || !a.en_ped) return hipSuccess;
-    if (sa.work) {
-        // cutoff on: compact the tile pairs that have to be evaluated, then a resident grid takes contiguous runs of them
-        hipError_t e = hipMemsetAsync(const_cast<int*>(sa.work_count), 0, sizeof(int), st);
-        if (e != hipSuccess) return e;
-        const bool whole = sa.t_lo == 0 && sa.t_hi == sa.n_t;      // a shard also looks at partners behind it
-        if (sa.n_strips > 0)
-            hipLaunchKernelGGL(sfm_pair_list2_kernel, dim3((sa.t_hi - sa.t_lo + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), dim3(BLOCK), 0, st,
-                               a.tile_box, a.tile_vmax, sa, a.ped.lam, const_cast<uint32_t*>(sa.work), const_cast<int*>(sa.work_count));
-        else
+// cutoff on: compact the tile pairs that have to be evaluated (the work list of the pair kernel)
+hipError_t launch_sym_list(const TickArgs& a, const SymArgs& sa, hipStream_t st) {
+    if (a.N <= 1 || !a.en_ped || !sa.work) return hipSuccess;
+    hipError_t e = hipMemsetAsync(const_cast<int*>(sa.work_count), 0, sizeof(int), st);
+    if (e != hipSuccess) return e;
+    const bool whole = sa.t_lo == 0 && sa.t_hi == sa.n_t;      // a shard also looks at partners behind it
+    if (sa.n_strips > 0)
+        hipLaunchKernelGGL(sfm_pair_list2_kernel, dim3((sa.t_hi - sa.t_lo + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), dim3(BLOCK), 0, st,
+                           a.tile_box, a.tile_vmax, sa, a.ped.lam, const_cast<uint32_t*>(sa.work), const_cast<int*>(sa.work_count));
+    else
         hipLaunchKernelGGL(sfm_pair_list_kernel, dim3((sa.t_hi - sa.t_lo + 255) / 256, whole ? sa.n_t / 2 + 1 : sa.n_t), dim3(256), 0, st,
                            a.tile_box, a.tile_vmax, sa.n_t, sa.t_lo, sa.t_hi, a.ped.lam, a.cut_scale, a.cut_pad,
                            const_cast<uint32_t*>(sa.work), const_cast<int*>(sa.work_count));
-        e = hipGetLastError();
-        if (e != hipSuccess) return e;
-        // a few times more workgroups than fit at once (8 per CU): short runs interleave better with the geometry kernel's
-        // workgroups and even out the tail; measured best 4x at 256 tiles, 16x from 1024 tiles on
+    return hipGetLastError();
+}
+
+hipError_t launch_sym_pair(bool rad, const TickArgs& a, const SymArgs& sa, hipStream_t st) {
+    if (a.N <= 1 || !a.en_ped) return hipSuccess;
+    if (sa.work) {
+        // a resident grid takes contiguous runs of the list: a few times more workgroups than fit at once (8 per CU), short runs
+        // interleave better with the geometry kernel's workgroups and even out the tail; measured best 4x at 256 tiles, 16x from
+        // 1024 tiles on
         const int rounds = std::min(16, std::max(2, sa.n_t / 64));
         if (rad) hipLaunchKernelGGL(sfm_pair_sym_kernel<true>, dim3(256 * 8 * rounds), dim3(BLOCK), 0, st, a.pk_cur, a.radius, a.ped, sa);
         else hipLaunchKernelGGL(sfm_pair_sym_kernel<false>, dim3(256 * 8 * rounds), dim3(BLOCK), 0, st, a.pk_cur, a.radius, a.ped, sa);

@@ -334,3 +334,9 @@ class SfmEngine:
 
     def kernel_variant(self):
         return self._lib.sfm_kernel_variant(self._h).decode()
+
+    def pair_work(self):
+        """(tile-pair work items, Moussaid terms evaluated) of the symmetric pair kernel in the last tick."""
+        items, terms = C.c_longlong(0), C.c_longlong(0)
+        self._check(self._lib.sfm_get_pair_work(self._h, C.byref(items), C.byref(terms)), "sfm_get_pair_work")
+        return items.value, terms.value

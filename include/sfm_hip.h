@@ -212,6 +212,11 @@ int sfm_get_timing(SfmHandle* h, float* elapsed_ms, int* ticks, int* launches);
 int sfm_profile_dominant_kernel(SfmHandle* h, int reps, float* avg_us);
 /* Name of the pair kernel variant the last tick used (for profiles), static storage. */
 const char* sfm_kernel_variant(const SfmHandle* h);
+/* Work the symmetric pair kernel did in the last tick (measurement only; no reference counterpart -- the reference
+ * always evaluates all N(N-1) ordered pairs, forces.py:74-117): tile-pair work items (whole 2-D grid, or the compacted
+ * list when the provably-negligible tile pairs are cut) and the Moussaid terms evaluated for them (one per unordered
+ * pair of a two-sided item).  SFM_ERR_STATE if the last tick used the ordered kernel. */
+int sfm_get_pair_work(SfmHandle* h, long long* tile_pair_items, long long* pair_terms);
 int sfm_abi_version(void);
 
 #ifdef __cplusplus

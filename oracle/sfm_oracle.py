@@ -109,7 +109,7 @@ def wrapped_angle_diff(u, w):
     return out, raw
 
 
-def moussaid_term(e, dist, dv, p: Interaction, theta_tol=0.0):
+def moussaid_term(e, dist, dv, p: Interaction, theta_tol=0.0, diagnostics=True):
     """Angular interaction of Moussaid et al. 2009 as coded in forces.py:85-115 (ped-ped) and
     forces.py:241-270 (ped-obstacle).  ``e`` unit direction towards the other body (k components),
     ``dist`` the (possibly radius-reduced) distance, ``dv`` = v_self - v_other.
@@ -129,6 +129,8 @@ def moussaid_term(e, dist, dv, p: Interaction, theta_tol=0.0):
     F = f_v[..., None] * t                                   # :112
     F[..., 0] += f_th * (-t[..., 1])                         # :89-91,113  n = (-t_y, t_x, 0)
     F[..., 1] += f_th * t[..., 0]
+    if not diagnostics:                                      # plain forces only (the CPU timing leg of bench.py)
+        return F, None, None
     if theta_tol > 0.0:
         near = (np.abs(theta) < theta_tol) | (np.abs(np.abs(raw) - np.pi) < theta_tol)
         with np.errstate(invalid="ignore"):
@@ -167,7 +169,7 @@ def acceleration_force(loc, vel, waypoint, target_speed, tau):
 # A3  pedestrian force (N x N)
 # --------------------------------------------------------------------------------------------------
 def pedestrian_force(loc, vel, radius, p: Interaction, use_ped_radius=False, chunk=256,
-                     theta_tol=0.0, rows=None):
+                     theta_tol=0.0, rows=None, diagnostics=True):
     """PedestrianForce._get_force (forces.py:74-117) streamed over i-chunks.
 
     Pair (i,j), j != i (stateutils.all_diffs removes the diagonal, stateutils.py:41-49):
@@ -188,9 +190,12 @@ def pedestrian_force(loc, vel, radius, p: Interaction, use_ped_radius=False, chu
         dv = vel[s:e_, None, :] - vel[None, :, :]
         if use_ped_radius:
             dist = dist - (radius[s:e_, None] + radius[None, :])   # forces.py:80-82
-        f, ex, mg = moussaid_term(e, dist, dv, p, theta_tol)
+        f, ex, mg = moussaid_term(e, dist, dv, p, theta_tol, diagnostics)
         off_diag = (idx[None, :] != np.arange(s, e_)[:, None])
         f = np.where(off_diag[..., None], f, 0.0)                  # drop j == i (select, so NaN-safe)
+        if not diagnostics:
+            F[s - i0:e_ - i0] = f.sum(axis=1)
+            continue
         ex = np.where(off_diag, ex, 0.0)
         mg = np.where(off_diag, mg, 0.0)
         F[s - i0:e_ - i0] = f.sum(axis=1)
