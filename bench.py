@@ -144,7 +144,7 @@ def cpu_baseline(sc, forces, cfg, budget_s=15.0):
             reps += 1
         dn = (time.perf_counter() - t0) / reps
     if limiter is not None:
-        limiter.unset()
+        limiter.restore_original_limits()
     out["numpy_dense_1core"] = {"value": 1.0 / dn, "unit": "ticks/s", "cores": 1, "kind": "port", "n_pedestrians": m,
                                 "ns_per_pair": dn * 1e9 / (m * (m - 1.0)),
                                 "sample": f"{reps} ticks of acceleration + pedestrian force + cap on the first {m} pedestrians; "

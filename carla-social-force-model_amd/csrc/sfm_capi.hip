@@ -747,7 +747,7 @@ static void fill_args(SfmHandle* h, TickArgs& a, uint32_t flags) {
     // keeps the boxes current; needs the whole crowd on this handle and the symmetric path
     const bool lite_ok = p.enabled[SFM_FORCE_PEDESTRIAN] && h->tile_box && !h->z3 && !h->rad && h->slab && h->i_begin == 0 &&
                          h->i_end == h->N && h->sym_mode != 0 && p.pedestrian.gamma > 0.f && p.pedestrian.lambda >= 0.f;
-    const bool lite = lite_ok && !cut && h->cut_mode == 2;   // opt-in (SFM_CUTOFF=2): at N ~ 4096 it measured no net gain
+    const bool lite = lite_ok && !cut && h->cut_mode == 2;   // opt-in (SFM_CUTOFF=2): see DESIGN.md 3.5 for why it does not pay yet
     a.tile_box = (cut || lite) ? h->tile_box + (size_t)h->box_cur * h->n_t : nullptr;
     a.tile_vmax = (cut || lite) ? h->tile_vmax + (size_t)h->box_cur * h->n_t : nullptr;
     a.tile_box_out = lite ? h->tile_box + (size_t)(h->box_cur ^ 1) * h->n_t : nullptr;
@@ -822,7 +822,8 @@ static SymArgs make_sym_args(const SfmHandle* h, const TickArgs& a, int tps, int
     const bool lite = a.tile_box_out != nullptr;
     const bool list = a.tile_box && !lite;
     return SymArgs{h->slab, h->tile_flag, h->n_t, slab_stride(h->n_t), h->dpp_dir, debug_steps,
-                   list ? h->work : nullptr, list ? h->work_count : nullptr, lite ? a.tile_box : nullptr, lite ? a.tile_vmax : nullptr,
+                   list ? h->work : nullptr, list ? h->work_count : nullptr, lite ? a.tile_box : nullptr,
+                   (lite || list) ? a.tile_vmax : nullptr,
                    a.cut_scale, a.cut_pad, stamps, h->strip_box, h->strip_vmax, tps, n_strips,
                    h->i_begin / WAVE, (h->i_end + WAVE - 1) / WAVE};
 }

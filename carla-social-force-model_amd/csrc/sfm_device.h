@@ -109,14 +109,16 @@ struct TickArgs {
 // Symmetric (antisymmetry-exploiting) pedestrian-force path, single shard only.
 struct SymArgs {
     float2* slab;        // [n_t][stride]: slab[u][i] = -A-less force on pedestrian i from all pedestrians of tile u
-    int* tile_flag;      // [n_t]: a coincident valid pair touches this tile -> exact recompute in the epilogue
+    int* tile_flag;      // [n_t]: unused since round 2 (a coincident pair now announces itself as a NaN in the slab)
     int n_t;             // number of 64-pedestrian tiles
     int stride;          // n_t * 64
     int dir;             // lane direction of the DPP wavefront rotate (+1: lane l receives lane l+1), calibrated at init
     int debug_steps;     // < 0: normal; >= 0: run only this many systolic steps per wave (timing probe, wrong results)
     const uint32_t* work;    // cutoff on: compacted list of (bx | shift << 16) tile-pair items, else null
     const int* work_count;
-    // "lite" cutoff for small crowds (no list): each workgroup tests its own tile pair and leaves if negligible
+    // "lite" cutoff for small crowds (no list): each workgroup tests its own tile pair and leaves if negligible (box != null);
+    // vmax (largest speed per tile, this tick's input state) is set whenever a cutoff is on, list or lite: the pair kernel
+    // then also skips the systolic steps whose 64 pairs are all beyond the reach of the two tiles' speeds
     const float4* box;
     const float* vmax;
     float cut_scale, cut_pad;

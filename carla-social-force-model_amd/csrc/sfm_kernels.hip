@@ -17,6 +17,7 @@
 #include "sfm_device.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace sfm {
 
@@ -129,6 +130,49 @@ __device__ __forceinline__ void moussaid(const IxConst& c, float dx, float dy, f
     gy = fmaf(e1, ty, gy);
     gy = fmaf(g, tx, gy);
     if (Z3) gz = fmaf(e1, tz, gz);
+}
+
+// The same interaction for the symmetric kernel's planar fast path, arranged for the fewest issued instructions:
+//   (dx,dy) = other - self and d2 = dx^2 + dy^2 come from the caller (it has already tested d2 against the reach);
+//   (wx,wy) = lambda (v_self - v_other) -- both velocities are pre-multiplied by lambda once per tile, so D = w + e is one
+//   fma per component and e itself is never formed: sin / cos of the angle come out scaled by d, S = t x (dx,dy) = d sin,
+//   C = t . (dx,dy) = d cos, and the half-angle ratio is S / (d + |C|).
+// d2 is NOT padded: a coincident pair gives rsq(0) = inf -> d = NaN -> a NaN term, which the epilogue takes as the
+// signal to recompute the tile with the exact body (the reference's conventions for zero vectors, forces.py:97,105).
+template <bool RAD>
+__device__ __forceinline__ void moussaid_planar(const IxConst& c, float dx, float dy, float d2, float wx, float wy, float rsum,
+                                                float& cx, float& cy) {
+    const float rinv = rsq(d2);
+    const float d = d2 * rinv;
+    const float Dx = fmaf(dx, rinv, wx), Dy = fmaf(dy, rinv, wy);
+    const float D2 = fmaf(Dx, Dx, fmaf(Dy, Dy, TINY));
+    const float rD = rsq(D2);
+    const float Dn = D2 * rD;                                          // |D|
+    const float tx = Dx * rD, ty = Dy * rD;
+    const float S = fmaf(tx, dy, -(ty * dx));                          // d sin(angle(e) - angle(t))
+    const float C = fmaf(tx, dx, ty * dy);                             // d cos
+    const float r = S * rcp(d + fabsf(C));                             // tan(angle / 2) folded into [-1, 1] (see atan2_unit)
+    const float z = r * r;
+    float p = -0.0095607885413262813f;
+    p = fmaf(p, z, 0.049113825228842972f);
+    p = fmaf(p, z, -0.11980885478692463f);
+    p = fmaf(p, z, 0.1988547939908939f);
+    p = fmaf(p, z, -0.28058826128196529f);
+    p = fmaf(p, z, 0.39942748114880167f);
+    p = fmaf(p, z, -0.66664186893326649f);
+    p = fmaf(p, z, 1.9999998228145017f);
+    const float a = p * r;
+    const float ang = (C < 0.0f) ? (copysignf(3.14159265358979324f, S) - a) : a;
+    const float theta = fmaf(-c.eg, Dn, ang);                          // forces.py:101
+    const float q = Dn * theta;
+    const float q2 = q * q;
+    const float deff = RAD ? d - rsum : d;
+    const float aL = deff * (rD * c.c1);
+    const float e1 = ex2(fmaf(q2, c.k1, aL));
+    const float e2 = ex2(fmaf(q2, c.k2, aL));
+    const float g = copysignf(e2, theta);
+    cx = fmaf(e1, tx, -(g * ty));
+    cy = fmaf(e1, ty, g * tx);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -1104,7 +1148,11 @@ __global__ void sfm_dpp_probe_kernel(int* out) {       // which way does wave_ro
     out[lane] = __builtin_amdgcn_update_dpp(0, lane, 0x134, 0xf, 0xf, false);
 }
 
-template <bool RAD>
+// CUT: the provably negligible part of a tile pair is not evaluated.  reach = the distance beyond which a
+// term is below 2^-40 A given the largest speeds of the two tiles (tiles_negligible's bound, per pair instead of per box):
+// a systolic step whose 64 pairs are ALL farther apart than that costs two subtractions, two fmas, a compare and the
+// rotation.  The test is on the pair's own distance, so it needs no agreement with anything else.
+template <bool RAD, bool CUT>
 __global__ __launch_bounds__(BLOCK) void sfm_pair_sym_kernel(const float4* __restrict__ pk, const float* __restrict__ radius,
                                                              const IxConst c, const SymArgs sa) {
     __shared__ float2 s_fi[WAVES_PER_BLOCK][WAVE];
@@ -1154,7 +1202,6 @@ __global__ __launch_bounds__(BLOCK) void sfm_pair_sym_kernel(const float4* __res
     if (sa.debug_steps >= 0) nsteps = sa.debug_steps;
 
     float fxi = 0.f, fyi = 0.f, fxj = 0.f, fyj = 0.f;
-    int flag = 0;                                  // max of the bit patterns of rsq(d2) (positive floats order like ints)
     int i_end_loc = lane;
     if (ta >= 0) {
         const float4 pj = pk[tb * WAVE + lane];
@@ -1162,25 +1209,35 @@ __global__ __launch_bounds__(BLOCK) void sfm_pair_sym_kernel(const float4* __res
         const float4 pi0 = pk[ta * WAVE + i_loc0];
         float rj = 0.f, ri = 0.f;                    // use_ped_radius: the radii travel with their pedestrians
         if (RAD) { rj = radius[tb * WAVE + lane]; ri = radius[ta * WAVE + i_loc0]; }
-        // lite cutoff (tested while the two loads above are in flight): every term of this tile pair is provably
-        // < 2^-40 A -> nothing to do; the epilogue applies the same test and does not read this pair's slab rows
-        if (sa.box && !sa.work && shift != 0 &&
-            tiles_negligible(sa.box[ta], sa.vmax[ta], sa.box[tb], sa.vmax[tb], c.lam, sa.cut_scale, sa.cut_pad)) {
-            if (sa.stamps && threadIdx.x == 0) {
-                const size_t b = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
-                sa.stamps[3 * b] = t_start; sa.stamps[3 * b + 1] = t_start; sa.stamps[3 * b + 2] = ~0ull;
+        float reach2 = __builtin_inff();             // CUT: squared distance beyond which a term is < 2^-40 A (uniform)
+        if (CUT && shift != 0) {
+            // lite cutoff (tested while the two loads above are in flight): every term of this tile pair is provably
+            // < 2^-40 A -> nothing to do; the epilogue applies the same test and does not read this pair's slab rows
+            if (sa.box && !sa.work &&
+                tiles_negligible(sa.box[ta], sa.vmax[ta], sa.box[tb], sa.vmax[tb], c.lam, sa.cut_scale, sa.cut_pad)) {
+                if (sa.stamps && threadIdx.x == 0) {
+                    const size_t b = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+                    sa.stamps[3 * b] = t_start; sa.stamps[3 * b + 1] = t_start; sa.stamps[3 * b + 2] = ~0ull;
+                }
+                return;
             }
-            return;
+            const float reach = fmaf(sa.cut_scale, fmaf(c.lam, sa.vmax[ta] + sa.vmax[tb], 1.0f), sa.cut_pad);
+            reach2 = reach * reach;
         }
-        float xi = pi0.x, yi = pi0.y, vxi = pi0.z, vyi = pi0.w;
+        // lambda v travels with i / stays with j: D = lambda (v_i - v_j) + e is then one fma per component
+        float xi = pi0.x, yi = pi0.y, uxi = c.lam * pi0.z, uyi = c.lam * pi0.w;
+        const float ujx = c.lam * pj.z, ujy = c.lam * pj.w;
         auto step = [&](bool both) {
-            float cx = 0.f, cy = 0.f, cz = 0.f, rinv;
-            moussaid<false, RAD, false>(c, pj.x - xi, pj.y - yi, 0.f, vxi - pj.z, vyi - pj.w, 0.f, RAD ? ri + rj : 0.f, cx, cy, cz, rinv);
-            flag = max(flag, __float_as_int(rinv));
-            fxi += cx;
-            fyi += cy;
-            if (both) { fxj -= cx; fyj -= cy; }
-            xi = rot1(xi); yi = rot1(yi); vxi = rot1(vxi); vyi = rot1(vyi);
+            const float dx = pj.x - xi, dy = pj.y - yi;
+            const float d2 = fmaf(dx, dx, dy * dy);
+            if (!CUT || __any(!(d2 > reach2))) {
+                float cx, cy;
+                moussaid_planar<RAD>(c, dx, dy, d2, uxi - ujx, uyi - ujy, RAD ? ri + rj : 0.f, cx, cy);
+                fxi += cx;
+                fyi += cy;
+                if (both) { fxj -= cx; fyj -= cy; }
+            }
+            xi = rot1(xi); yi = rot1(yi); uxi = rot1(uxi); uyi = rot1(uyi);
             if (RAD) ri = rot1(ri);
             fxi = rot1(fxi); fyi = rot1(fyi);
         };
@@ -1199,8 +1256,6 @@ __global__ __launch_bounds__(BLOCK) void sfm_pair_sym_kernel(const float4* __res
             for (int s = 0; s < nsteps; ++s) step(true);
         }
         i_end_loc = (lane + sa.dir * (sig0 + nsteps)) & (WAVE - 1);
-        const float fmax_ = wave_max(__int_as_float(flag));
-        if (fmax_ >= COINCIDENT_RINV && lane == 0) { sa.tile_flag[ta] = 1; sa.tile_flag[tb] = 1; }
     }
     s_fi[wave][i_end_loc] = make_float2(fxi, fyi);
     s_fj[wave][lane] = make_float2(fxj, fyj);
@@ -1252,6 +1307,7 @@ template <bool RAD>
 __global__ __launch_bounds__(EPI_BLOCK) void sfm_sym_epilogue_kernel(const TickArgs a, const SymArgs sa) {
     __shared__ float2 s_sum[EPI_WAVES][WAVE];
     __shared__ float2 s_exact[WAVE];
+    __shared__ int s_bad[EPI_WAVES];
     const int tid = threadIdx.x;
     const int lane = tid & (WAVE - 1);
     const int wave = uniform(tid >> 6);
@@ -1345,8 +1401,21 @@ __global__ __launch_bounds__(EPI_BLOCK) void sfm_sym_epilogue_kernel(const TickA
         }
     }
     s_sum[wave][lane] = acc;
-    const bool exact = a.en_ped && (sa.tile_flag[t] != 0);       // uniform per workgroup
+    // A coincident pair leaves a NaN (moussaid_planar) in the sums of both pedestrians: any non-finite partial sum sends the
+    // whole tile through the exact body below.
+    {
+        const bool bad = !(fabsf(acc.x) < __builtin_inff()) || !(fabsf(acc.y) < __builtin_inff());
+        if (lane == 0) s_bad[wave] = 0;
+        if (bad) s_bad[wave] = 1;                                  // same wave, LDS operations in order
+    }
     __syncthreads();
+    bool exact = false;                                            // uniform per workgroup
+    if (a.en_ped) {
+        int any_bad = 0;
+#pragma unroll
+        for (int w = 0; w < EPI_WAVES; ++w) any_bad |= s_bad[w];
+        exact = uniform(any_bad) != 0;
+    }
 
     // 2. coincident pairs in this tile: recompute its rows with the exact ordered body (rare)
     if (exact) {
@@ -1373,7 +1442,6 @@ __global__ __launch_bounds__(EPI_BLOCK) void sfm_sym_epilogue_kernel(const TickA
     }
     if (exact) __syncthreads();
     if (wave != 0) return;
-    if (exact && lane == 0) sa.tile_flag[t] = 0;      // re-armed for the next tick
     const bool live = i < i_end;                           // padding rows ride along (wave reductions below) but never store
 
     // 4. lane-parallel epilogue for the 64 pedestrians of the tile
@@ -1544,19 +1612,25 @@ hipError_t launch_sym_list(const TickArgs& a, const SymArgs& sa, hipStream_t st)
     return hipGetLastError();
 }
 
+template <bool RAD, bool CUT>
+static void launch_sym_pair_t(dim3 grid, const TickArgs& a, const SymArgs& sa, hipStream_t st) {
+    static const int pad_lds = getenv("SFM_PAIR_LDS") ? atoi(getenv("SFM_PAIR_LDS")) : 0;   // experiment: limits the resident workgroups per CU
+    hipLaunchKernelGGL((sfm_pair_sym_kernel<RAD, CUT>), grid, dim3(BLOCK), (size_t)pad_lds, st, a.pk_cur, a.radius, a.ped, sa);
+}
+
 hipError_t launch_sym_pair(bool rad, const TickArgs& a, const SymArgs& sa, hipStream_t st) {
     if (a.N <= 1 || !a.en_ped) return hipSuccess;
+    dim3 grid(sa.n_t, sa.n_t / 2 + 1);
     if (sa.work) {
         // a resident grid takes contiguous runs of the list: a few times more workgroups than fit at once (8 per CU), short runs
         // interleave better with the geometry kernel's workgroups and even out the tail; measured best 4x at 256 tiles, 16x from
         // 1024 tiles on
         const int rounds = std::min(16, std::max(2, sa.n_t / 64));
-        if (rad) hipLaunchKernelGGL(sfm_pair_sym_kernel<true>, dim3(256 * 8 * rounds), dim3(BLOCK), 0, st, a.pk_cur, a.radius, a.ped, sa);
-        else hipLaunchKernelGGL(sfm_pair_sym_kernel<false>, dim3(256 * 8 * rounds), dim3(BLOCK), 0, st, a.pk_cur, a.radius, a.ped, sa);
-        return hipGetLastError();
+        grid = dim3(256 * 8 * rounds);
     }
-    if (rad) hipLaunchKernelGGL(sfm_pair_sym_kernel<true>, dim3(sa.n_t, sa.n_t / 2 + 1), dim3(BLOCK), 0, st, a.pk_cur, a.radius, a.ped, sa);
-    else hipLaunchKernelGGL(sfm_pair_sym_kernel<false>, dim3(sa.n_t, sa.n_t / 2 + 1), dim3(BLOCK), 0, st, a.pk_cur, a.radius, a.ped, sa);
+    const bool cut = sa.vmax != nullptr;           // list or lite cutoff: the per-step reach test is on as well
+    if (rad) { if (cut) launch_sym_pair_t<true, true>(grid, a, sa, st); else launch_sym_pair_t<true, false>(grid, a, sa, st); }
+    else { if (cut) launch_sym_pair_t<false, true>(grid, a, sa, st); else launch_sym_pair_t<false, false>(grid, a, sa, st); }
     return hipGetLastError();
 }
 

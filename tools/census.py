@@ -35,3 +35,10 @@ u, c = np.unique(key, return_counts=True)
 print("distinct CUs", len(u), "workgroups per CU min/median/max", c.min(), np.median(c), c.max())
 for t in (2000, 5000, 8000, 11000, 14000):
     print(f"resident workgroups at t={t} ns:", int(((s <= t) & (e > t)).sum()))
+# per-CU finishing time and lifetime spread (load balance picture)
+life = e - s
+last = np.array([e[key == k].max() for k in u])
+work = np.array([life[key == k].sum() for k in u])
+print("per-CU last end ns: min/median/max", last.min(), np.median(last), last.max())
+print("per-CU sum of lifetimes ns: min/median/max", work.min(), np.median(work), work.max())
+print("lifetime ns percentiles", np.percentile(life, [0, 10, 25, 50, 75, 90, 100]))
