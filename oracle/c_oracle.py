@@ -74,8 +74,10 @@ def max_threads():
 
 
 def tick(loc, vel, waypoint, target_speed, radius, crossing, geom: O.Geometry, prm: O.OracleParams, dt,
-         rows=None, theta_tol=0.0, nthreads=0):
-    """Returns (dict name -> (n,3), total (n,3), v_new (n,3), exposure (n,), absum (n,)) for rows [i0,i1)."""
+         rows=None, theta_tol=0.0, nthreads=0, plain=None):
+    """Returns (dict name -> (n,3), total (n,3), v_new (n,3), exposure (n,), absum (n,)) for rows [i0,i1).
+    ``plain``: optional float64 (n,) array that receives the unweighted sum of term magnitudes (absum without the fp32
+    conditioning weights)."""
     lib = load()
     N = loc.shape[0]
     i0, i1 = (0, N) if rows is None else rows
@@ -101,7 +103,8 @@ def tick(loc, vel, waypoint, target_speed, radius, crossing, geom: O.Geometry, p
     rc = lib.oracle_tick(C.c_int(N), C.c_int(i0), C.c_int(i1), *(C.c_void_p(a.ctypes.data) for a in arrs),
                          C.c_void_p(cm.ctypes.data), C.byref(P), C.byref(gb), C.byref(gs), C.byref(gd),
                          C.c_void_p(forces.ctypes.data), C.c_void_p(v_new.ctypes.data), C.c_void_p(expo.ctypes.data),
-                         C.c_void_p(absum.ctypes.data), C.c_double(theta_tol), C.c_int(nthreads))
+                         C.c_void_p(absum.ctypes.data), C.c_double(theta_tol), C.c_int(nthreads),
+                         C.c_void_p(plain.ctypes.data if plain is not None else None))
     assert rc == 0
     per = {name: forces[k] for k, name in enumerate(O.FORCE_NAMES) if prm.enabled[name]}
     return per, forces[5], v_new, expo, absum

@@ -39,7 +39,7 @@ static double unit(const double* a, int k, double* out) {
 
 /* forces.py:85-115 / :241-270.  e: unit direction (k comps), dist, dv = v_self - v_other.  Adds into F[0..k). */
 static double moussaid(const OIx* p, const double* e, double dist, const double* dv, int k, double* F, double theta_tol,
-                       double* mag) {
+                       double* mag, double* plain) {
     double D[3] = {0, 0, 0}, t[3] = {0, 0, 0};
     for (int c = 0; c < k; ++c) D[c] = p->lam * dv[c] + e[c];
     const double Dn = unit(D, k, t);
@@ -62,6 +62,7 @@ static double moussaid(const OIx* p, const double* e, double dist, const double*
         const double xt = fabs(a) + (p->n * B * theta) * (p->n * B * theta);
         *mag += fabs(fv) * (1.0 + (2.0 * (p->n_prime * B) * (p->n_prime * B) * at + xv) * res)
               + fabs(ft) * (1.0 + (2.0 * (p->n * B) * (p->n * B) * at + xt) * res);
+        *plain += fabs(fv) + fabs(ft);                  /* the same sum without the conditioning weights */
     }
     if (theta_tol > 0.0 && (fabs(theta) < theta_tol || fabs(fabs(raw) - M_PI) < theta_tol) && !isnan(ft)) return 2.0 * fabs(ft);
     return 0.0;
@@ -81,11 +82,12 @@ static int nearest(const double* pts, int o0, int o1, double x, double y) {
 
 /* One tick for rows [i0, i1).  loc/vel/wp: N x 3.  forces: 6 x n x 3 (5 forces + total), vel_out: n x 3,
  * expo: n (sign/wrap exposure of the Moussaid terms), absum: n (sum of the magnitudes of all force terms, the
- * scale of the fp32 rounding error); either may be NULL. */
+ * scale of the fp32 rounding error, each Moussaid term weighted by its fp32 conditioning), plain_absum: n (the same sum
+ * unweighted: absum / plain_absum - 1 is the mean conditioning weight a parity test leaned on); any may be NULL. */
 int oracle_tick(int N, int i0, int i1, const double* loc, const double* vel, const double* wp, const double* tspeed,
                 const double* radius, const uint8_t* crossing, const OParams* P, const OGeo* borders,
                 const OGeo* statics, const OGeo* dynamics, double* forces, double* vel_out, double* expo,
-                double* absum, double theta_tol, int nthreads) {
+                double* absum, double theta_tol, int nthreads, double* plain_absum) {
     const int n = i1 - i0;
     if (n <= 0) return 0;
     memset(forces, 0, sizeof(double) * 18 * (size_t)n);
@@ -103,7 +105,7 @@ int oracle_tick(int N, int i0, int i1, const double* loc, const double* vel, con
         double* Ft = forces + ((size_t)5 * n + r) * 3;
         const double* xi = loc + 3 * (size_t)i;
         const double* vi = vel + 3 * (size_t)i;
-        double ex = 0.0, mg = 0.0;
+        double ex = 0.0, mg = 0.0, pl = 0.0;
         if (P->enabled[0]) {                                    /* forces.py:46-53, stateutils.py:7-15 */
             double to[2] = {wp[3 * (size_t)i] - xi[0], wp[3 * (size_t)i + 1] - xi[1]}, e[2];
             unit(to, 2, e);
@@ -111,6 +113,7 @@ int oracle_tick(int N, int i0, int i1, const double* loc, const double* vel, con
             Fa[1] = 1.0 / P->tau * (tspeed[i] * e[1] - vi[1]);
             Fa[2] = 1.0 / P->tau * (tspeed[i] * 0.0 - vi[2]);
             mg += (fabs(tspeed[i]) + sqrt(vi[0] * vi[0] + vi[1] * vi[1] + vi[2] * vi[2])) / P->tau;
+            pl += (fabs(tspeed[i]) + sqrt(vi[0] * vi[0] + vi[1] * vi[1] + vi[2] * vi[2])) / P->tau;
         }
         if (P->enabled[1]) {                                    /* forces.py:74-117 */
             for (int j = 0; j < N; ++j) {
@@ -121,7 +124,7 @@ int oracle_tick(int N, int i0, int i1, const double* loc, const double* vel, con
                 double dist = unit(diff, 3, e);
                 if (P->use_ped_radius) dist -= radius[i] + radius[j];
                 double dv[3] = {vi[0] - vj[0], vi[1] - vj[1], vi[2] - vj[2]};
-                ex += moussaid(&P->ped, e, dist, dv, 3, Fp, theta_tol, &mg);
+                ex += moussaid(&P->ped, e, dist, dv, 3, Fp, theta_tol, &mg, &pl);
             }
         }
         if (P->enabled[2] && borders && borders->K > 0) {       /* forces.py:138-179 */
@@ -137,7 +140,7 @@ int oracle_tick(int N, int i0, int i1, const double* loc, const double* vel, con
                 const double mag = P->border_a * exp(-1.0 * dist / P->border_b);
                 Fb[0] += e[0] * mag;
                 Fb[1] += e[1] * mag;
-                if (!(crossing && crossing[i])) mg += fabs(mag);
+                if (!(crossing && crossing[i])) { mg += fabs(mag); pl += fabs(mag); }
             }
             if (crossing && crossing[i]) { Fb[0] *= 0.0; Fb[1] *= 0.0; }
         }
@@ -157,7 +160,7 @@ int oracle_tick(int N, int i0, int i1, const double* loc, const double* vel, con
                 if (P->use_ped_radius) dist -= radius[i];
                 double dv[2] = {vi[0] - (g->extra ? g->extra[2 * k] : 0.0), vi[1] - (g->extra ? g->extra[2 * k + 1] : 0.0)};
                 double f2[3] = {0, 0, 0};
-                ex += moussaid(ix, e, dist, dv, 2, f2, theta_tol, &mg);
+                ex += moussaid(ix, e, dist, dv, 2, f2, theta_tol, &mg, &pl);
                 F[0] += f2[0];
                 F[1] += f2[1];
             }
@@ -172,6 +175,7 @@ int oracle_tick(int N, int i0, int i1, const double* loc, const double* vel, con
         for (int c = 0; c < 3; ++c) vel_out[3 * (size_t)r + c] = v[c] * fac;
         if (expo) expo[r] = ex;
         if (absum) absum[r] = mg;
+        if (plain_absum) plain_absum[r] = pl;
     }
     return 0;
 }

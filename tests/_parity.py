@@ -67,3 +67,23 @@ def check_velocity_conditioned(got, ref, expo, summed, dt, rtol=RTOL):
     strict = rtol * np.linalg.norm(ref[ok], axis=1) + dt * np.nan_to_num(expo[ok]) * 1.001 + 1e-12
     return int((err > strict).sum())          # how many needed the conditioning term
 
+
+
+def diagnostics(got, ref, absum, plain, expo):
+    """What a passing check_force leaned on, so that the conditioned tolerance cannot hide a regression:
+      plain_rel  = max_i |dF_i| / max_i |F_i|            (no conditioning, no exposure: the headline 'relative error')
+      row_rel_p99 = 99th percentile of |dF_i| / |F_i|
+      max_amp    = max_i (A_i / sum_j |f_ij| - 1)         (mean conditioning weight of pedestrian i's terms)
+      max_expo_rel = max_i exposure_i / max(|F_i|, A_i)   (how large a discontinuity allowance was, relative to the scale)
+      n_expo     = pedestrians with a non-zero exposure."""
+    got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    ok = ~(np.isnan(ref).any(axis=1))
+    err = np.linalg.norm(got[ok] - ref[ok], axis=1)
+    nrm = np.linalg.norm(ref[ok], axis=1)
+    scale = np.maximum(nrm, np.nan_to_num(absum[ok]))
+    pl = np.nan_to_num(plain[ok])
+    return {"plain_rel": float(err.max() / max(nrm.max(), 1e-300)) if err.size else 0.0,
+            "row_rel_p99": float(np.percentile(err / np.maximum(nrm, 1e-300), 99)) if err.size else 0.0,
+            "max_amp": float(np.max(np.nan_to_num(absum[ok]) / np.maximum(pl, 1e-300) - 1.0)) if err.size else 0.0,
+            "max_expo_rel": float(np.max(np.nan_to_num(expo[ok]) / np.maximum(scale, 1e-300))) if err.size else 0.0,
+            "n_expo": int((np.nan_to_num(expo[ok]) > 0).sum())}

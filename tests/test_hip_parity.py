@@ -306,12 +306,21 @@ def test_property_checks_at_baseline_size():
         eng.close()
 
 
-@pytest.mark.parametrize("name", ["c3", "c4", "c5"])
+# ceilings on what the conditioned tolerance of _parity.check_force was allowed to absorb at full size (measured values in
+# profiles/r02_full_size_parity_diagnostics.txt; a regression in the kernels shows up here before it can hide in the
+# conditioning): plain max|dF| / max|F|, 99th percentile of the per-pedestrian |dF| / |F|, mean conditioning weight per
+# pedestrian, pedestrians that got a discontinuity allowance at all (its size relative to the scale is printed, not bounded:
+# a sign(theta) flip of a dominant lateral term is legitimately of order one)
+FULL_SIZE_CEILINGS = {"plain_rel": 5e-6, "row_rel_p99": 1e-5, "max_amp": 1.0, "n_expo": 200}   # n_expo: of 768 sampled rows x 2 rounds
+
+
+@pytest.mark.parametrize("name", ["c2", "c3", "c4", "c5"])
 def test_baseline_configs_at_full_size_row_samples(name):
-    """BASELINE configs 3-5 at their full sizes, in the configuration bench.py runs them (spatial packing, tile cutoff,
-    two-level list at c5, geometry kernel): the summed force and v' of three row blocks -- first, middle, last in the
-    caller's order, i.e. scattered over the internal tiles -- against the C oracle, after one tick and, for the state
-    the device reached by itself, after 3 more ticks (re-synchronised: the oracle starts from the device's state)."""
+    """BASELINE configs 2-5 at their full sizes, in the configuration bench.py runs them (c2: acceleration + pedestrian force
+    through the symmetric kernel; c3-c5: spatial packing, tile cutoff, two-level list at c5, geometry kernel): the summed
+    force and v' of three row blocks -- first, middle, last in the caller's order, i.e. scattered over the internal tiles --
+    against the C oracle, after one tick and, for the state the device reached by itself, after 3 more ticks
+    (re-synchronised: the oracle starts from the device's state).  Prints and bounds what the tolerance leaned on."""
     sc, forces = scenarios.baseline_scenario(name)
     cfg = default_sfm_config(forces)
     prm = O.OracleParams.from_config(cfg)
@@ -325,6 +334,7 @@ def test_baseline_configs_at_full_size_row_samples(name):
         eng.set_dynamic_obstacles(sc.dynamic_obstacles, sc.dynamic_vel)
         eng.upload_state(sc.loc, sc.vel, sc.waypoint, sc.target_speed, sc.radius, None)
         loc, vel, wp3 = sc.loc, sc.vel, sc.waypoint
+        worst = {}
         for rnd in range(2):
             geom = O.Geometry(sc.borders, sc.border_centers, sc.border_lengths, sc.static_obstacles, sc.dynamic_obstacles,
                               sc.dynamic_vel)
@@ -333,14 +343,23 @@ def test_baseline_configs_at_full_size_row_samples(name):
             v = eng.velocities()
             assert np.isfinite(F).all() and np.isfinite(v).all()
             for r in blocks:
+                plain = np.zeros(r[1] - r[0])
                 per, total, v_new, expo, absum = c_oracle.tick(loc, vel, wp3, sc.target_speed, sc.radius, np.zeros(n, bool),
-                                                               geom, prm, 0.05, rows=r, theta_tol=P.THETA_TOL)
+                                                               geom, prm, 0.05, rows=r, theta_tol=P.THETA_TOL, plain=plain)
                 P.check_force("total", F[r[0]:r[1]], total, absum, expo)
-                P.check_velocity(v[r[0]:r[1]], v_new, expo, 0.05)
+                vw = P.check_velocity(v[r[0]:r[1]], v_new, expo, 0.05)
+                d = P.diagnostics(F[r[0]:r[1]], total, absum, plain, expo)
+                d["v_rel"] = vw
+                for k, val in d.items():
+                    worst[k] = max(worst.get(k, 0), val)
             if rnd == 0:
                 eng.run(2, redraw=False)                               # the device carries on by itself ...
                 loc, vel, wp = eng.state()                             # ... and the oracle restarts from where it got to
                 wp3 = np.zeros_like(loc); wp3[:, :2] = wp
+        print(f"\nfull-size parity {name} ({eng.kernel_variant()}): " + "  ".join(f"{k}={v:.3g}" for k, v in sorted(worst.items())))
+        for k, ceil in FULL_SIZE_CEILINGS.items():
+            assert worst[k] <= ceil, f"{name}: {k} = {worst[k]:.3g} above its ceiling {ceil}"
+        assert worst["v_rel"] <= P.RTOL
     finally:
         eng.close()
 
