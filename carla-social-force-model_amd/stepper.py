@@ -18,15 +18,59 @@ from .engine import SfmEngine
 
 
 def shard_bounds(n, n_pad, rank, world):
-    """Contiguous row block of ``rank``: the padded record count is split evenly (it is a multiple of 256,
-    hence of any world size up to 8 ranks x 32 lanes), so every rank contributes an equal-sized chunk to
-    the all-gather; rows at or beyond ``n`` are padding."""
+    """Contiguous row block of ``rank`` under the EQUAL split: the padded record count is split evenly (it is a
+    multiple of 256, hence of any world size up to 8 ranks x 32 lanes); rows at or beyond ``n`` are padding.
+    Returns (lo, hi, chunk).  The starting point of ``ShardedStepper``; ``balanced_bounds`` moves it from there."""
     if n_pad % world:
         raise ValueError(f"padded size {n_pad} not divisible by world size {world}")
     chunk = n_pad // world
     lo = min(rank * chunk, n)
     hi = min((rank + 1) * chunk, n)
     return lo, hi, chunk
+
+
+TILE = 64
+
+
+def equal_bounds(n, n_pad, world):
+    """[b_0 = 0, b_1, ..., b_world = n]: the equal split as a bounds list."""
+    return [shard_bounds(n, n_pad, r, world)[0] for r in range(world)] + [n]
+
+
+def balanced_bounds(bounds, costs, n, damping=0.7, min_rows=TILE):
+    """Move the shard boundaries so that every rank carries the same cost (a rank in the middle of
+    the map has two neighbours whose boundary pairs it evaluates one-sided, a rank at the edge one).
+
+    ``costs[r]`` is what rank r spent on rows [bounds[r], bounds[r+1]) (any positive measure; the stepper uses the pair
+    kernel's evaluated terms, a deterministic function of state and partition).  The cost is taken as uniform over a
+    rank's rows; the new boundary k sits where the cumulative cost reaches k/G of the total, moved only ``damping`` of the way
+    (the one-sided work travels with the boundary, so the estimate is re-measured after every move), rounded to whole
+    64-row tiles and kept at least ``min_rows`` apart.  Pure function of its arguments: every rank computes the same list."""
+    world = len(bounds) - 1
+    if world == 1:
+        return [0, n]
+    rows = [bounds[r + 1] - bounds[r] for r in range(world)]
+    total = float(sum(costs))
+    if total <= 0.0 or any(c < 0 for c in costs):
+        return list(bounds)
+    cum = [0.0]
+    for c in costs:
+        cum.append(cum[-1] + float(c))
+    new = [0]
+    r = 0
+    for k in range(1, world):
+        target = total * k / world
+        while r < world - 1 and cum[r + 1] < target:
+            r += 1
+        frac = (target - cum[r]) / max(cum[r + 1] - cum[r], 1e-300)
+        ideal = bounds[r] + frac * rows[r]
+        moved = bounds[k] + damping * (ideal - bounds[k])
+        b = int(round(moved / TILE)) * TILE
+        b = max(b, new[-1] + min_rows)
+        b = min(b, n - (world - k) * min_rows)
+        new.append(b)
+    new.append(n)
+    return new
 
 
 class _DevSpan:
@@ -97,6 +141,14 @@ class HipShardEngine:
     def resort(self):
         self.engine.resort()
 
+    def work(self):
+        """What this rank's last tick cost, for the boundary balancing: the Moussaid terms the pair kernel evaluated
+        (a deterministic function of state and partition); 0 when the ordered kernel ran (no measure: boundaries stay)."""
+        try:
+            return self.engine.pair_work()[1]
+        except Exception:
+            return 0
+
     auto_resort = True          # a whole-crowd handle re-packs its rows by itself (SFM_RESORT_EVERY)
 
     def state(self):
@@ -110,34 +162,108 @@ class HipShardEngine:
 
 
 class ShardedStepper:
-    """K ticks of the CARLA-free loop across ``world`` ranks."""
+    """K ticks of the CARLA-free loop across ``world`` ranks.
 
-    def __init__(self, engine, scenario, rank=0, world=1, group=None, redraw=True, resort_every=None):
+    Rank r owns rows [bounds[r], bounds[r+1]) of the (spatially packed) row order: whole 64-row tiles, equal shares to
+    start with.  Every ``resort_every`` ticks the rows are re-packed (all ranks identically) and -- ``balance`` -- the
+    boundaries move so that every rank carries the same pair work (``balanced_bounds``; the measure is the engine's
+    ``work()``, all-gathered, so every rank computes the same new boundaries)."""
+
+    def __init__(self, engine, scenario, rank=0, world=1, group=None, redraw=True, resort_every=None, balance=None):
         self.engine, self.rank, self.world, self.group, self.redraw = engine, rank, world, group, redraw
         self.n, self.n_pad = engine.load(scenario, redraw=redraw)
-        self.lo, self.hi, self.chunk = shard_bounds(self.n, self.n_pad, rank, world)
+        self.bounds = equal_bounds(self.n, self.n_pad, world)
+        self.lo, self.hi = self.bounds[rank], self.bounds[rank + 1]
         engine.set_shard(self.lo, self.hi)
         self.ticks_done = 0
         # rows are kept spatially packed (compact 64-row tiles); pedestrians walk, so the packing is renewed every
         # `resort_every` ticks.  One rank: the engine does it itself.  Shards: gather the owner-only per-row arrays,
-        # then every rank re-packs identically and carries on with rows [lo, hi) of the new order.
+        # then every rank re-packs identically and carries on with its rows of the new order.
         if resort_every is None:
             resort_every = int(os.environ.get("SFM_RESORT_EVERY", "64"))
         self.resort_every = resort_every
         self.since_resort = 0
+        if balance is None:
+            balance = os.environ.get("SFM_BALANCE", "1") != "0"
+        self.balance = balance and world > 1 and hasattr(engine, "work")
+        self._plans = {}
 
+    # ---- the exchange ---------------------------------------------------------------------------------------------
     def exchange(self, force=False):
-        """The one collective of a tick: in-place all-gather of the packed records.  ``force`` issues it on a
-        single-rank group too (used to exercise the RCCL path on a one-GPU box)."""
+        """The one collective of a tick: all-gather of the packed records.  ``force`` issues it on a single-rank group
+        too (used to exercise the RCCL path on a one-GPU box)."""
         if self.world == 1 and not force:
             return
         self._gather(self.engine.packed())
 
     def _gather(self, buffers):
+        """Every rank's own rows of each buffer reach every other rank.  Equal shares: ONE in-place
+        all_gather_into_tensor on the buffer itself.  Unequal shares (balanced boundaries): the own rows go into this
+        rank's slot of a staging tensor padded to the largest share, one in-place all_gather_into_tensor on it, and one
+        indexed copy spreads the other ranks' rows over the buffer (two small kernels beside the collective)."""
         import torch.distributed as dist
+        b = self.bounds
+        sizes = [b[r + 1] - b[r] for r in range(self.world)]
+        chunk = sizes[0]
+        even = all(sz == chunk for sz in sizes[:-1]) and sizes[-1] <= chunk and all(b[r] == r * chunk for r in range(self.world))
         for buf, width in buffers:
-            mine = buf[self.rank * self.chunk * width:(self.rank + 1) * self.chunk * width]
-            dist.all_gather_into_tensor(buf, mine, group=self.group)
+            if even and buf.numel() >= self.world * chunk * width:
+                mine = buf[self.rank * chunk * width:(self.rank + 1) * chunk * width]
+                dist.all_gather_into_tensor(buf[:self.world * chunk * width], mine, group=self.group)
+                continue
+            stage, src, dst = self._plan(buf, width, sizes)
+            rows = buf.view(-1, width)
+            cmax = stage.shape[1]
+            stage[self.rank, :sizes[self.rank]].copy_(rows[self.lo:self.hi])
+            dist.all_gather_into_tensor(stage.view(-1), stage[self.rank].reshape(-1), group=self.group)
+            rows.index_copy_(0, dst, stage.view(self.world * cmax, width).index_select(0, src))
+
+    def _plan(self, buf, width, sizes):
+        """(staging tensor [world, largest share, width], source rows in it, destination rows in the buffer) for the
+        current boundaries; cached per (buffer, boundaries)."""
+        import torch
+        key = (buf.data_ptr(), width, tuple(self.bounds))
+        plan = self._plans.get(key)
+        if plan is None:
+            if len(self._plans) > 16:
+                self._plans.clear()
+            cmax = max(sizes)
+            stage = torch.zeros((self.world, cmax, width), dtype=buf.dtype, device=buf.device)
+            src, dst = [], []
+            for r in range(self.world):
+                if r == self.rank or sizes[r] == 0:
+                    continue
+                k = np.arange(sizes[r], dtype=np.int64)
+                src.append(r * cmax + k)
+                dst.append(self.bounds[r] + k)
+            cat = lambda parts: torch.as_tensor(np.concatenate(parts) if parts else np.zeros(0, np.int64), device=buf.device)
+            plan = (stage, cat(src), cat(dst))
+            self._plans[key] = plan
+        return plan
+
+    # ---- stepping -------------------------------------------------------------------------------------------------
+    def _repack(self):
+        """All ranks: bring every row's owner-only data up to date everywhere, re-pack identically, then (balance) move
+        the boundaries by the work each rank measured in its last tick."""
+        if self.world > 1:
+            self._gather(self.engine.row_data())
+        self.engine.resort()
+        if self.balance:
+            import torch
+            import torch.distributed as dist
+            mine = float(self.engine.work())
+            dev = self.engine.packed()[0][0].device
+            t = torch.zeros(self.world, dtype=torch.float64, device=dev)
+            t[self.rank] = mine
+            dist.all_reduce(t, group=self.group)
+            self.set_bounds(balanced_bounds(self.bounds, [float(v) for v in t.cpu().tolist()], self.n))
+        self.since_resort = 0
+
+    def set_bounds(self, bounds):
+        assert len(bounds) == self.world + 1 and bounds[0] == 0 and bounds[-1] == self.n
+        self.bounds = list(bounds)
+        self.lo, self.hi = self.bounds[self.rank], self.bounds[self.rank + 1]
+        self.engine.set_shard(self.lo, self.hi)
 
     def step(self, ticks=1):
         driver_resorts = self.resort_every > 0 and not (self.world == 1 and getattr(self.engine, "auto_resort", False))
@@ -146,10 +272,7 @@ class ShardedStepper:
         else:
             for _ in range(ticks):
                 if driver_resorts and self.since_resort >= self.resort_every:
-                    if self.world > 1:
-                        self._gather(self.engine.row_data())
-                    self.engine.resort()
-                    self.since_resort = 0
+                    self._repack()
                 self.engine.run(1, redraw=self.redraw)
                 self.exchange()
                 self.since_resort += 1

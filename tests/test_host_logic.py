@@ -170,3 +170,21 @@ def test_shard_bounds_cover_everything_once():
         assert rows == list(range(n))
     with pytest.raises(ValueError):
         shard_bounds(100, 256, 0, 3)
+
+
+def test_balanced_bounds_evens_out_a_lopsided_cost():
+    """stepper.balanced_bounds: boundaries move towards equal cost, stay whole tiles, never cross, never lose the ends."""
+    from carla_social_force_model_amd.stepper import balanced_bounds, equal_bounds
+    n = 262144
+    b = equal_bounds(n, n, 8)
+    density = lambda r: 1.0 if r in (0, 7) else 1.25            # interior ranks pay for two boundaries
+    first = None
+    for _ in range(6):
+        costs = [(b[r + 1] - b[r]) * density(r) for r in range(8)]
+        spread = max(costs) / (sum(costs) / 8)
+        first = first or spread
+        b = balanced_bounds(b, costs, n)
+        assert b[0] == 0 and b[-1] == n and all(x % 64 == 0 for x in b) and all(b[r + 1] - b[r] >= 64 for r in range(8))
+    assert first > 1.04 and spread < 1.005
+    assert balanced_bounds([0, 128, 256], [0.0, 0.0], 256) == [0, 128, 256]     # no measure: boundaries stay
+    assert balanced_bounds([0, 256], [5.0], 256) == [0, 256]

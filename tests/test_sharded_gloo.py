@@ -84,6 +84,11 @@ class OracleShardEngine:
         d[:n] = d[:n][order]
         self.ids = self.ids[order]
 
+    def work(self):
+        """A deliberately lopsided cost measure (rows x (1 + first own row / n)): the balancing then moves every
+        boundary, shares become unequal and the padded exchange path of ShardedStepper._gather is what runs."""
+        return (self.hi - self.lo) * (1.0 + 2.0 * self.lo / max(self.n, 1))
+
     def state(self):
         v = self.buf.view(self.n_pad, 4).numpy()
         o = self.own.view(self.n_pad, 4).numpy()
@@ -103,16 +108,17 @@ def _scenario():
     return scenarios.make_scenario(N, 2024, n_borders=12, border_len=(5.0, 20.0))
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, balance):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        st = ShardedStepper(OracleShardEngine(CFG, 0.05), _scenario(), rank=rank, world=world, resort_every=RESORT_EVERY)
+        st = ShardedStepper(OracleShardEngine(CFG, 0.05), _scenario(), rank=rank, world=world, resort_every=RESORT_EVERY,
+                            balance=balance)
         st.step(TICKS)
         loc, vel, wp = st.gather_state()
         if rank == 0:
-            np.savez(out, loc=loc, vel=vel, wp=wp)
+            np.savez(out, loc=loc, vel=vel, wp=wp, bounds=np.array(st.bounds))
     finally:
         dist.destroy_process_group()
 
@@ -123,14 +129,19 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_sharded_equals_single_rank(world, tmp_path):
+@pytest.mark.parametrize("world,balance", [(2, False), (4, False), (2, True), (4, True)])
+def test_sharded_equals_single_rank(world, balance, tmp_path):
     single = ShardedStepper(OracleShardEngine(CFG, 0.05), _scenario(), resort_every=RESORT_EVERY)
     single.step(TICKS)
     loc1, vel1, wp1 = single.gather_state()
     out = str(tmp_path / "sharded.npz")
-    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), out, balance), nprocs=world, join=True)
     z = np.load(out)
     assert np.array_equal(z["loc"], loc1) and np.array_equal(z["vel"], vel1) and np.array_equal(z["wp"], wp1)
+    shares = np.diff(z["bounds"])
+    assert z["bounds"][0] == 0 and z["bounds"][-1] == N and (shares > 0).all()
+    if balance:                                      # the boundaries moved: unequal shares of whole tiles, padded exchange
+        assert len(set(shares[:-1].tolist())) > 1 or shares[0] != -(-N // 256) * 256 // world
+        assert (z["bounds"][1:-1] % 64 == 0).all()
     # and the crowd actually moved / interacted
     assert np.linalg.norm(loc1 - _scenario().loc) > 1.0
