@@ -20,6 +20,8 @@ hipError_t launch_arrived(const float4* pk, const float4* own, int N, float thr2
 hipError_t launch_sym_list(const TickArgs& a, const SymArgs& sa, hipStream_t st);
 hipError_t launch_sym_pair(bool rad, const TickArgs& a, const SymArgs& sa, hipStream_t st);
 hipError_t launch_sym_epilogue(bool rad, const TickArgs& a, const SymArgs& sa, hipStream_t st);
+hipError_t launch_schedule(const int* cost, int n_t, uint32_t* work, int* count, hipStream_t st);
+int sym_item_count(int n_t);
 hipError_t launch_strip_bounds(const float4* box, const float* vmax, int n_t, int tps, int n_strips, float4* sbox, float* svmax,
                                hipStream_t st);
 hipError_t launch_geometry(bool rad, const TickArgs& a, hipStream_t st);
@@ -109,7 +111,8 @@ struct SfmHandle {
     uint32_t* work = nullptr;
     int* work_count = nullptr;
     size_t work_cap = 0;
-    int cut_mode = -1;                     // SFM_CUTOFF: 0 off, 1 list-based, 2 lite, -1 auto (list-based for N >= 8192)
+    int cut_mode = -1;                     // SFM_CUTOFF: 0 off, 1 list-based, 2 lite (+ dealt item order), -1 auto (list-based for N >= 8192)
+    int sched_mode = -1;                   // SFM_SCHED=0: lite cutoff without the cost-balanced item order (A/B)
     unsigned long long* stamps = nullptr;  // SFM_STAMPS diagnostic: per-workgroup timestamps of the symmetric pair kernel
     // spatial reordering: row s holds the caller's pedestrian perm[s] (strips in x, each sorted by y: sfm_reorder.hip), so the 64-tiles
     // are compact squares; every download translates back.  Identity when off.
@@ -131,6 +134,10 @@ struct SfmHandle {
     float r_max = 0.f;
     bool used_sym = false;
     bool last_list = false;                // the last symmetric tick ran from the tile-pair list (cutoff on)
+    // scheduled lite cutoff (mid-sized whole crowds): per-item step counts of the last tick and whether `work` holds a dealt order
+    int* cost = nullptr;
+    size_t cost_cap = 0;
+    bool sched_valid = false, last_sched = false;
 
     uint32_t seed = 0;
     float world_side = 0.f, arrive_thr = 2.0f;
@@ -256,6 +263,8 @@ int sfm_create(const SfmParams* params, int device_id, SfmHandle** out) {
     if (ov) h->sym_mode = atoi(ov);
     ov = getenv("SFM_CUTOFF");
     if (ov) h->cut_mode = atoi(ov);
+    ov = getenv("SFM_SCHED");
+    if (ov) h->sched_mode = atoi(ov);
     ov = getenv("SFM_REORDER");
     if (ov) h->reorder_mode = atoi(ov);
     ov = getenv("SFM_GEO_SLICES");
@@ -325,6 +334,7 @@ int sfm_destroy(SfmHandle* h) {
     if (h->strip_vmax) hipFree(h->strip_vmax);
     if (h->work) hipFree(h->work);
     if (h->work_count) hipFree(h->work_count);
+    if (h->cost) hipFree(h->cost);
     free_geo(h->borders); free_geo(h->statics); free_geo(h->dynamics);
     if (h->aux) { hipStreamSynchronize(h->aux); hipStreamDestroy(h->aux); }
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
@@ -623,6 +633,8 @@ int sfm_upload_state(SfmHandle* h, int N, const float* x, const float* y, const 
         const size_t items = (size_t)h->n_t * (size_t)(h->n_t / 2 + 1);
         if (h->n_t < 65536 && items > h->work_cap) { HIP_TRY(h, dev_realloc(h->work, items)); h->work_cap = items; }
         if (!h->work_count) HIP_TRY(h, dev_realloc(h->work_count, (size_t)1));
+        if (h->n_t <= 128 && items > h->cost_cap) { HIP_TRY(h, dev_realloc(h->cost, items)); h->cost_cap = items; }
+        h->sched_valid = false;
     }
     return SFM_OK;
 }
@@ -747,7 +759,11 @@ static void fill_args(SfmHandle* h, TickArgs& a, uint32_t flags) {
     // keeps the boxes current; needs the whole crowd on this handle and the symmetric path
     const bool lite_ok = p.enabled[SFM_FORCE_PEDESTRIAN] && h->tile_box && !h->z3 && !h->rad && h->slab && h->i_begin == 0 &&
                          h->i_end == h->N && h->sym_mode != 0 && p.pedestrian.gamma > 0.f && p.pedestrian.lambda >= 0.f;
-    const bool lite = lite_ok && !cut && h->cut_mode == 2;   // opt-in (SFM_CUTOFF=2): see DESIGN.md 3.5 for why it does not pay yet
+    // opt-in (SFM_CUTOFF=2), with the cost-balanced item order (SymArgs::cost) when N <= 8192.  Measured on c2 (N = 4096 in a
+    // 128 m square, round 2): the reach of a walking crowd is ~77 m, so only 16 % of the systolic steps are out of reach in the
+    // steady state; balanced, the pair kernel drops 15.5 -> 14.9 us while the tile boxes, the dealer and the periodic
+    // re-pack add 2.2 us to the tick.  Off by default below 8192 pedestrians.
+    const bool lite = lite_ok && !cut && h->cut_mode == 2;
     a.tile_box = (cut || lite) ? h->tile_box + (size_t)h->box_cur * h->n_t : nullptr;
     a.tile_vmax = (cut || lite) ? h->tile_vmax + (size_t)h->box_cur * h->n_t : nullptr;
     a.tile_box_out = lite ? h->tile_box + (size_t)(h->box_cur ^ 1) * h->n_t : nullptr;
@@ -797,6 +813,7 @@ static int resort_rows(SfmHandle* h) {
     h->perm_stale = true;
     h->ticks_since_sort = 0;
     h->boxes_valid = false;
+    h->sched_valid = false;                        // the tiles are other pedestrians now: last tick's costs mean nothing
     return SFM_OK;
 }
 
@@ -821,11 +838,12 @@ static void strip_shape(const SfmHandle* h, int* tps, int* n_strips) {
 static SymArgs make_sym_args(const SfmHandle* h, const TickArgs& a, int tps, int n_strips, int debug_steps, unsigned long long* stamps) {
     const bool lite = a.tile_box_out != nullptr;
     const bool list = a.tile_box && !lite;
+    const bool sched = lite && h->cost && h->sched_mode != 0 && (size_t)h->n_t * (size_t)(h->n_t / 2 + 1) <= h->cost_cap;
     return SymArgs{h->slab, h->tile_flag, h->n_t, slab_stride(h->n_t), h->dpp_dir, debug_steps,
-                   list ? h->work : nullptr, list ? h->work_count : nullptr, lite ? a.tile_box : nullptr,
+                   (list || sched) ? h->work : nullptr, (list || sched) ? h->work_count : nullptr, lite ? a.tile_box : nullptr,
                    (lite || list) ? a.tile_vmax : nullptr,
                    a.cut_scale, a.cut_pad, stamps, h->strip_box, h->strip_vmax, tps, n_strips,
-                   h->i_begin / WAVE, (h->i_end + WAVE - 1) / WAVE};
+                   h->i_begin / WAVE, (h->i_end + WAVE - 1) / WAVE, sched ? h->cost : nullptr, -1};
 }
 
 static int run_ticks(SfmHandle* h, int ticks, uint32_t flags) {
@@ -899,12 +917,19 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags) {
         }
         if (sym) {
             const SymArgs sa = make_sym_args(h, a, tps, n_strips, h->debug_steps, h->stamps);
-            h->last_list = sa.work != nullptr;
-            if (sa.work && n_strips > 0) {
+            h->last_list = sa.work != nullptr && !sa.cost;
+            h->last_sched = sa.cost != nullptr;
+            if (sa.cost && !h->sched_valid) {     // no costs yet (new crowd / new packing): deal the items in their natural order
+                HIP_TRY(h, hipMemsetAsync(h->cost, 0, sizeof(int) * (size_t)h->n_t * (size_t)(h->n_t / 2 + 1), h->stream));
+                HIP_TRY(h, launch_schedule(h->cost, h->n_t, h->work, h->work_count, h->stream));
+                h->sched_valid = true;
+                ++launches;
+            }
+            if (sa.work && !sa.cost && n_strips > 0) {
                 HIP_TRY(h, launch_strip_bounds(a.tile_box, a.tile_vmax, h->n_t, tps, n_strips, h->strip_box, h->strip_vmax, h->stream));
                 ++launches;
             }
-            if (sa.work) {
+            if (sa.work && !sa.cost) {
                 HIP_TRY(h, launch_sym_list(a, sa, h->stream));
                 ++launches;
             }
@@ -954,7 +979,7 @@ int sfm_profile_dominant_kernel(SfmHandle* h, int reps, float* avg_us) {
     if (h->used_sym) a.geo = nullptr;
     const SymArgs sa = make_sym_args(h, a, tps, n_strips, -1, nullptr);
     if (a.tile_box) HIP_TRY(h, launch_tile_bounds(a.pk_cur, h->z3 ? a.zv_cur : nullptr, h->N, const_cast<float4*>(a.tile_box), const_cast<float*>(a.tile_vmax), h->stream));
-    if (sa.work && n_strips > 0)
+    if (sa.work && !sa.cost && n_strips > 0)
         HIP_TRY(h, launch_strip_bounds(a.tile_box, a.tile_vmax, h->n_t, tps, n_strips, h->strip_box, h->strip_vmax, h->stream));
     if (h->used_sym) HIP_TRY(h, launch_sym_list(a, sa, h->stream));      // the list is built once, outside the timed launches
     HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
@@ -1195,6 +1220,16 @@ int sfm_get_pair_work(SfmHandle* h, long long* tile_pair_items, long long* pair_
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     const long long t_own = (h->i_end + WAVE - 1) / WAVE - h->i_begin / WAVE;
     long long items, diag_items = (t_own + 1) / 2;
+    if (h->last_sched) {                           // per-item step counts of the last tick: 64 pairs per executed step
+        const size_t n_slots = (size_t)h->n_t * (size_t)(h->n_t / 2 + 1);
+        std::vector<int> c(n_slots);
+        HIP_TRY(h, hipMemcpy(c.data(), h->cost, sizeof(int) * n_slots, hipMemcpyDeviceToHost));
+        long long steps = 0, live = 0;
+        for (size_t id = (size_t)h->n_t; id < n_slots; ++id) { steps += c[id]; live += c[id] > 0; }
+        if (tile_pair_items) *tile_pair_items = live + diag_items;
+        if (pair_terms) *pair_terms = steps * (long long)WAVE + t_own * (long long)(WAVE * WAVE / 2);
+        return SFM_OK;
+    }
     if (h->last_list) {
         int cnt = 0;
         HIP_TRY(h, hipMemcpy(&cnt, h->work_count, sizeof(int), hipMemcpyDeviceToHost));

@@ -130,6 +130,11 @@ struct SymArgs {
     int tps, n_strips;
     int t_lo, t_hi;      // tiles of this handle's rows (a shard; whole crowd: 0, n_t).  Pairs with a tile outside are
                          // evaluated one-sided: the other side belongs to another rank, which evaluates it itself
+    // Scheduled lite cutoff (mid-sized whole crowds): `work` holds ALL tile-pair items in the order sfm_schedule_items dealt
+    // them (one item per workgroup) and every workgroup leaves the number of systolic steps it executed, 0..64, in
+    // cost[shift * n_t + bx] -- the next tick's order is dealt from those.  cost == null: off.
+    int* cost;
+    int sched_block;     // epilogue launch: index of the extra workgroup that deals the next tick's order (-1: none)
 };
 
 }  // namespace sfm

@@ -1157,6 +1157,7 @@ __global__ __launch_bounds__(BLOCK) void sfm_pair_sym_kernel(const float4* __res
                                                              const IxConst c, const SymArgs sa) {
     __shared__ float2 s_fi[WAVES_PER_BLOCK][WAVE];
     __shared__ float2 s_fj[WAVES_PER_BLOCK][WAVE];
+    __shared__ int s_cnt[WAVES_PER_BLOCK];
     const int tid = threadIdx.x;
     const int lane = tid & (WAVE - 1);
     const int wave = uniform(tid >> 6);
@@ -1203,6 +1204,8 @@ __global__ __launch_bounds__(BLOCK) void sfm_pair_sym_kernel(const float4* __res
 
     float fxi = 0.f, fyi = 0.f, fxj = 0.f, fyj = 0.f;
     int i_end_loc = lane;
+    int executed = 0;                             // systolic steps this wave evaluated (uniform)
+    bool negligible = false;                      // lite cutoff: the whole tile pair is provably below 2^-40 A
     if (ta >= 0) {
         const float4 pj = pk[tb * WAVE + lane];
         const int i_loc0 = (lane + sa.dir * sig0) & (WAVE - 1);
@@ -1213,17 +1216,11 @@ __global__ __launch_bounds__(BLOCK) void sfm_pair_sym_kernel(const float4* __res
         if (CUT && shift != 0) {
             // lite cutoff (tested while the two loads above are in flight): every term of this tile pair is provably
             // < 2^-40 A -> nothing to do; the epilogue applies the same test and does not read this pair's slab rows
-            if (sa.box && !sa.work &&
-                tiles_negligible(sa.box[ta], sa.vmax[ta], sa.box[tb], sa.vmax[tb], c.lam, sa.cut_scale, sa.cut_pad)) {
-                if (sa.stamps && threadIdx.x == 0) {
-                    const size_t b = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
-                    sa.stamps[3 * b] = t_start; sa.stamps[3 * b + 1] = t_start; sa.stamps[3 * b + 2] = ~0ull;
-                }
-                return;
-            }
+            negligible = sa.box && tiles_negligible(sa.box[ta], sa.vmax[ta], sa.box[tb], sa.vmax[tb], c.lam, sa.cut_scale, sa.cut_pad);
             const float reach = fmaf(sa.cut_scale, fmaf(c.lam, sa.vmax[ta] + sa.vmax[tb], 1.0f), sa.cut_pad);
             reach2 = reach * reach;
         }
+      if (!negligible) {
         // lambda v travels with i / stays with j: D = lambda (v_i - v_j) + e is then one fma per component
         float xi = pi0.x, yi = pi0.y, uxi = c.lam * pi0.z, uyi = c.lam * pi0.w;
         const float ujx = c.lam * pj.z, ujy = c.lam * pj.w;
@@ -1236,6 +1233,7 @@ __global__ __launch_bounds__(BLOCK) void sfm_pair_sym_kernel(const float4* __res
                 fxi += cx;
                 fyi += cy;
                 if (both) { fxj -= cx; fyj -= cy; }
+                ++executed;
             }
             xi = rot1(xi); yi = rot1(yi); uxi = rot1(uxi); uyi = rot1(uyi);
             if (RAD) ri = rot1(ri);
@@ -1256,11 +1254,16 @@ __global__ __launch_bounds__(BLOCK) void sfm_pair_sym_kernel(const float4* __res
             for (int s = 0; s < nsteps; ++s) step(true);
         }
         i_end_loc = (lane + sa.dir * (sig0 + nsteps)) & (WAVE - 1);
+      }
     }
     s_fi[wave][i_end_loc] = make_float2(fxi, fyi);
     s_fj[wave][lane] = make_float2(fxj, fyj);
+    if (sa.cost && lane == 0) s_cnt[wave] = executed;
     __syncthreads();
-    if (shift == 0) {
+    if (sa.cost && tid == 0) sa.cost[shift * n_t + bx] = (s_cnt[0] + s_cnt[1]) + (s_cnt[2] + s_cnt[3]);
+    if (negligible) {
+        // nothing written: the epilogue applies the same (bitwise symmetric) test and does not read this pair's slab rows
+    } else if (shift == 0) {
         // waves 0,1 -> tile bx ; waves 2,3 -> tile bx + half_up
         if (tid < 2 * WAVE) {
             const int g = tid >> 6;                       // 0 or 1
@@ -1296,6 +1299,57 @@ __global__ __launch_bounds__(BLOCK) void sfm_pair_sym_kernel(const float4* __res
     }
 }
 
+// Deals the tile-pair items of the NEXT tick to the workgroups of the pair kernel (scheduled lite cutoff, whole crowd).
+// Under the per-step reach test a tile pair costs anything between nothing and 64 steps, all workgroups of a mid-sized crowd
+// are resident at once, and a CU's time is the sum of its eight: a corner tile's partners are mostly out of reach, a central
+// tile's are not.  The dispatcher places workgroup w on CU (w mod 256) -- round-robin over the 8 XCDs, then over an XCD's
+// CUs, observed on MI355X (tools/cu_map_probe.py); nothing but speed depends on it -- so the items are sorted by the
+// cost they had in the tick before (counting sort, 65 buckets) and dealt in rounds of 256, every other round backwards:
+// each CU gets one item of every cost octile.  One workgroup of `nthreads` threads.
+constexpr int SCHED_CUS = 256;
+__device__ void sfm_schedule_items(const int* __restrict__ cost, int n_t, uint32_t* __restrict__ work, int* __restrict__ count,
+                                   int tid, int nthreads, int* s_hist /* [66] */) {
+    const int n_slots = n_t * (n_t / 2 + 1);
+    const int half_up = (n_t + 1) >> 1;
+    auto active = [&](int id) {
+        const int shift = id / n_t, bx = id - shift * n_t;
+        if (shift == 0) return bx < half_up;
+        return !(!(n_t & 1) && shift == (n_t >> 1) && bx >= (n_t >> 1));
+    };
+    for (int q = tid; q < 66; q += nthreads) s_hist[q] = 0;
+    __syncthreads();
+    for (int id = tid; id < n_slots; id += nthreads)
+        if (active(id)) atomicAdd(&s_hist[64 - min(max(cost[id], 0), 64)], 1);      // bucket 0 = the most expensive
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int q = 0; q < 65; ++q) { const int c = s_hist[q]; s_hist[q] = run; run += c; }
+        s_hist[65] = run;                                                            // number of items
+        *count = run;
+    }
+    __syncthreads();
+    const int m = s_hist[65];
+    // position inside a bucket: first come, first served (an LDS atomic per item).  Which workgroup evaluates an item has no
+    // influence on any result -- every slab row is written exactly once whoever writes it -- so the arbitrary order inside a
+    // bucket only moves equal-cost items between CUs.
+    for (int id = tid; id < n_slots; id += nthreads) {
+        if (!active(id)) continue;
+        const int b = 64 - min(max(cost[id], 0), 64);
+        const int p = atomicAdd(&s_hist[b], 1);                                      // rank in the cost-descending order
+        const int round = p / SCHED_CUS, pos = p - round * SCHED_CUS;
+        const int width = min(SCHED_CUS, m - round * SCHED_CUS);
+        const int slot = round * SCHED_CUS + ((round & 1) ? (width - 1 - pos) : pos);
+        const int shift = id / n_t, bx = id - shift * n_t;
+        work[slot] = (uint32_t)bx | ((uint32_t)shift << 16);
+    }
+}
+
+__global__ __launch_bounds__(1024) void sfm_schedule_kernel(const int* __restrict__ cost, int n_t, uint32_t* __restrict__ work,
+                                                            int* __restrict__ count) {
+    __shared__ int s_hist[66];
+    sfm_schedule_items(cost, n_t, work, count, threadIdx.x, blockDim.x, s_hist);
+}
+
 // Epilogue of the symmetric path: one workgroup of 16 waves per tile of 64 pedestrians.  The waves split the
 // partner tiles of the slab column sum (all loads of a wave in flight at once, combined in LDS in a fixed
 // order) and wave 0 integrates the 64 pedestrians lane-parallel with coalesced loads and stores (geometry
@@ -1311,6 +1365,11 @@ __global__ __launch_bounds__(EPI_BLOCK) void sfm_sym_epilogue_kernel(const TickA
     const int tid = threadIdx.x;
     const int lane = tid & (WAVE - 1);
     const int wave = uniform(tid >> 6);
+    if (sa.sched_block >= 0 && (int)blockIdx.x == sa.sched_block) {  // one more extra workgroup: the next tick's item order
+        __shared__ int s_hist[66];
+        sfm_schedule_items(sa.cost, sa.n_t, const_cast<uint32_t*>(sa.work), const_cast<int*>(sa.work_count), tid, EPI_BLOCK, s_hist);
+        return;
+    }
     if (a.adv.M > 0 && (int)blockIdx.x >= a.adv.block0) {            // the extra workgroups: vehicles move on
         const int k = ((int)blockIdx.x - a.adv.block0) * EPI_WAVES + wave;
         if (k < a.adv.M) advance_vehicle(a.adv, k, lane, true);
@@ -1598,7 +1657,7 @@ hipError_t launch_geometry(bool rad, const TickArgs& a, hipStream_t st) {
 
 // cutoff on: compact the tile pairs that have to be evaluated (the work list of the pair kernel)
 hipError_t launch_sym_list(const TickArgs& a, const SymArgs& sa, hipStream_t st) {
-    if (a.N <= 1 || !a.en_ped || !sa.work) return hipSuccess;
+    if (a.N <= 1 || !a.en_ped || !sa.work || sa.cost) return hipSuccess;       // (scheduled mode: the order is dealt, not built)
     hipError_t e = hipMemsetAsync(const_cast<int*>(sa.work_count), 0, sizeof(int), st);
     if (e != hipSuccess) return e;
     const bool whole = sa.t_lo == 0 && sa.t_hi == sa.n_t;      // a shard also looks at partners behind it
@@ -1611,6 +1670,8 @@ hipError_t launch_sym_list(const TickArgs& a, const SymArgs& sa, hipStream_t st)
                            const_cast<uint32_t*>(sa.work), const_cast<int*>(sa.work_count));
     return hipGetLastError();
 }
+
+int sym_item_count(int n_t);
 
 template <bool RAD, bool CUT>
 static void launch_sym_pair_t(dim3 grid, const TickArgs& a, const SymArgs& sa, hipStream_t st) {
@@ -1626,7 +1687,7 @@ hipError_t launch_sym_pair(bool rad, const TickArgs& a, const SymArgs& sa, hipSt
         // interleave better with the geometry kernel's workgroups and even out the tail; measured best 4x at 256 tiles, 16x from
         // 1024 tiles on
         const int rounds = std::min(16, std::max(2, sa.n_t / 64));
-        grid = dim3(256 * 8 * rounds);
+        grid = sa.cost ? dim3(sym_item_count(sa.n_t)) : dim3(256 * 8 * rounds);    // scheduled: one dealt item per workgroup
     }
     const bool cut = sa.vmax != nullptr;           // list or lite cutoff: the per-step reach test is on as well
     if (rad) { if (cut) launch_sym_pair_t<true, true>(grid, a, sa, st); else launch_sym_pair_t<true, false>(grid, a, sa, st); }
@@ -1650,10 +1711,22 @@ hipError_t launch_strip_bounds(const float4* box, const float* vmax, int n_t, in
 hipError_t launch_sym_epilogue(bool rad, const TickArgs& a, const SymArgs& sa, hipStream_t st) {
     if (a.N <= 0) return hipSuccess;
     TickArgs b = a;
+    SymArgs sb = sa;
     b.adv.block0 = sa.t_hi - sa.t_lo;
     const int extra = a.adv.M > 0 ? (a.adv.M + EPI_WAVES - 1) / EPI_WAVES : 0;
-    if (rad) hipLaunchKernelGGL((sfm_sym_epilogue_kernel<true>), dim3(sa.t_hi - sa.t_lo + extra), dim3(EPI_BLOCK), 0, st, b, sa);
-    else hipLaunchKernelGGL((sfm_sym_epilogue_kernel<false>), dim3(sa.t_hi - sa.t_lo + extra), dim3(EPI_BLOCK), 0, st, b, sa);
+    const int sched = sa.cost ? 1 : 0;             // scheduled lite cutoff: one more workgroup deals the next tick's order
+    sb.sched_block = sched ? sa.t_hi - sa.t_lo + extra : -1;
+    if (rad) hipLaunchKernelGGL((sfm_sym_epilogue_kernel<true>), dim3(sa.t_hi - sa.t_lo + extra + sched), dim3(EPI_BLOCK), 0, st, b, sb);
+    else hipLaunchKernelGGL((sfm_sym_epilogue_kernel<false>), dim3(sa.t_hi - sa.t_lo + extra + sched), dim3(EPI_BLOCK), 0, st, b, sb);
+    return hipGetLastError();
+}
+
+// number of tile-pair items of a whole crowd of n_t tiles (what sfm_schedule_items deals): every unordered tile pair once +
+// the diagonal items (two diagonal tiles each)
+int sym_item_count(int n_t) { return n_t * (n_t - 1) / 2 + (n_t + 1) / 2; }
+
+hipError_t launch_schedule(const int* cost, int n_t, uint32_t* work, int* count, hipStream_t st) {
+    hipLaunchKernelGGL(sfm_schedule_kernel, dim3(1), dim3(1024), 0, st, cost, n_t, work, count);
     return hipGetLastError();
 }
 

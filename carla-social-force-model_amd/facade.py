@@ -53,14 +53,22 @@ class PedestrianSimulation:
     Keyword-only additions: ``device`` (GPU ordinal), ``record_states`` (the reference records the whole
     state every tick, pedestrian_state.py:100-104; switch off for long runs) and ``honour_file_keys``
     (read ``[acceleration_force] tau`` / ``max_speed_multiplier`` instead of the keys the reference looks
-    up)."""
+    up) and ``planar_tolerance``.
+
+    ``planar_tolerance`` (metres and m/s; default None = off) is a documented DEVIATION for large crowds on nearly flat
+    ground: the reference's pedestrian force and speed cap use 3-component vectors (pedestrian_state.py:17-19,
+    forces.py:74-117, stateutils.py:18-23), so by default any spread in z or any v_z sends the crowd through the 3-D
+    ordered kernel (exact).  With a tolerance, a crowd whose z stay within it of their median and whose |v_z| stay
+    below it is treated as planar -- z differences and v_z are dropped from the norms, v_z' comes back as 0 -- which
+    makes the symmetric pair kernel reachable from a CARLA client (walkers never have exactly equal z)."""
 
     def __init__(self, borders, border_section_info, obstacles, sfm_config, step_length, *, device=0,
-                 record_states=True, honour_file_keys=False):
+                 record_states=True, honour_file_keys=False, planar_tolerance=None):
         self.sfm_config, self.step_length = sfm_config, step_length
         self.borders, self.section_info = borders, border_section_info
         self.static_obstacles = obstacles
         self.record_states = record_states
+        self.planar_tolerance = planar_tolerance
         # dynamic obstacles as last reported by the simulator (update_dynamic_obstacles)
         self.dyn_obs_ids, self.dyn_obstacles, self.dyn_obs_heading = [], [], []
         self.dyn_obs_vel, self.dyn_obs_extent = [], []
@@ -99,7 +107,13 @@ class PedestrianSimulation:
             elif name == 'static_obstacle_force' and 'obstacles' in what:
                 self.engine.set_static_obstacles(what['obstacles'])
         self._staged.clear()
-        self.engine.upload_state(*peds.numeric_columns())
+        cols = peds.numeric_columns()
+        planar = None                                            # None: the engine decides (exactly flat crowds only)
+        if self.planar_tolerance is not None and len(cols[0]):
+            z, vz = np.asarray(cols[0])[:, 2], np.asarray(cols[1])[:, 2]
+            if np.max(np.abs(z - np.median(z))) <= self.planar_tolerance and np.max(np.abs(vz)) <= self.planar_tolerance:
+                planar = True
+        self.engine.upload_state(*cols, planar=planar)
 
     # ---- one simulation step --------------------------------------------------------------------------------
     def tick(self, sim_time):

@@ -30,6 +30,8 @@ def shard_bounds(n, n_pad, rank, world):
 
 
 TILE = 64
+ROW_COST_TERMS = 600             # HipShardEngine.work(): per-row cost of a tick outside the pair kernel, in pair terms
+GEOMETRY_ROW_COST_TERMS = 1000   # ... and of the border / obstacle forces
 
 
 def equal_bounds(n, n_pad, world):
@@ -103,6 +105,8 @@ class HipShardEngine:
         crossing = (sc.mode == 2) | (sc.mode == 3)
         e.upload_state(sc.loc, sc.vel, sc.waypoint, sc.target_speed, sc.radius, crossing)
         e.set_waypoint_stream(sc.seed, sc.world_side, 2.0)
+        en = e.params.enabled
+        self._has_geometry = bool((en[2] and len(sc.borders)) or (en[3] and len(sc.static_obstacles)) or (en[4] and len(sc.dynamic_obstacles)))
         self.n = sc.n
         _, self.n_pad = e.packed_state_ptr()
         return self.n, self.n_pad
@@ -145,9 +149,14 @@ class HipShardEngine:
         """What this rank's last tick cost, for the boundary balancing: the Moussaid terms the pair kernel evaluated
         (a deterministic function of state and partition); 0 when the ordered kernel ran (no measure: boundaries stay)."""
         try:
-            return self.engine.pair_work()[1]
+            terms = self.engine.pair_work()[1]
         except Exception:
             return 0
+        # ... plus what scales with the rows themselves (tile boxes, list building, epilogue; the geometry kernel when a
+        # border / obstacle force is on), in units of pair terms: fitted on c5 at G = 8 (tools/shard_probe.py:
+        # ~1.5 ns per row against ~1 ps per term)
+        lo, hi = self.engine.shard
+        return terms + (hi - lo) * (ROW_COST_TERMS + (GEOMETRY_ROW_COST_TERMS if self._has_geometry else 0))
 
     auto_resort = True          # a whole-crowd handle re-packs its rows by itself (SFM_RESORT_EVERY)
 

@@ -143,3 +143,40 @@ def test_host_loop_trajectory_tracks_reference():
             assert err <= 2e-5 * (k + 1), f"tick {k}: {err:.2e}"
     finally:
         sim.close()
+
+
+def test_planar_tolerance_is_an_opt_in_deviation():
+    """Default: any spread in z keeps the exact 3-D kernel (zspread_n64 goes through test_tick_through_facade that way).
+    With ``planar_tolerance`` a crowd on nearly flat ground (z within 2 cm, |v_z| ~ 1e-3) is handed to the planar path --
+    the symmetric kernel at this size -- and agrees with the reference evaluated on the exactly flat crowd."""
+    from carla_social_force_model_amd import scenarios
+    from carla_social_force_model_amd.config import default_sfm_config
+    cfg = default_sfm_config(("acceleration_force", "pedestrian_force"))
+    sc = scenarios.make_scenario(512, 909)
+    rng = np.random.default_rng(5)
+    bumpy_loc, bumpy_vel = sc.loc.copy(), sc.vel.copy()
+    bumpy_loc[:, 2] = np.float32(0.2) + rng.uniform(-0.01, 0.01, sc.n).astype(np.float32)
+    bumpy_vel[:, 2] = rng.uniform(-1e-3, 1e-3, sc.n).astype(np.float32)
+    prm = O.OracleParams.from_config(cfg)
+    with np.errstate(all="ignore"):
+        _, flat_total, _ = O.tick_forces(sc.loc, sc.vel, sc.waypoint, sc.target_speed, sc.radius, np.zeros(sc.n, bool),
+                                         O.Geometry(), prm)
+    flat_v = O.new_velocities(sc.vel, flat_total, sc.target_speed, 0.05)
+    variants = {}
+    for tol in (None, 0.05):
+        sim = PedestrianSimulation([], [], [], cfg, 0.05, planar_tolerance=tol)
+        try:
+            for i in range(sc.n):
+                sim.spawn_pedestrian((f"ped_{i}", i, bumpy_loc[i], bumpy_vel[i], sc.waypoint[i],
+                                      _mode_manager(f"ped_{i}", sc.target_speed[i], 1), 0.3, float(sc.target_speed[i])))
+            sim.tick(0.0)
+            variants[tol] = (sim.engine.kernel_variant(), sim.get_new_velocities()['vel'].copy())
+        finally:
+            sim.close()
+    assert "sfm_tick_kernel" in variants[None][0] and "true" in variants[None][0].split("<")[1].split(",")[1]   # 3-D ordered kernel
+    assert "sym" in variants[0.05][0]
+    v = variants[0.05][1]
+    assert np.all(v[:, 2] == 0.0)
+    assert np.allclose(v[:, :2], flat_v[:, :2], rtol=1e-5, atol=1e-7)
+    # and the deviation is small but real: the exact 3-D evaluation of the bumpy crowd is not the flat one
+    assert not np.array_equal(variants[None][1][:, :2], v[:, :2])

@@ -634,3 +634,32 @@ def test_recorded_run_matches_stepwise_downloads(n, monkeypatch):
     finally:
         for e in engs:
             e.close()
+
+
+def test_dealt_item_order_changes_nothing_but_time(monkeypatch):
+    """SFM_CUTOFF=2 (lite cutoff + per-step reach test) on a mid-sized crowd, with and without the cost-balanced deal of the
+    tile-pair items to the workgroups (sfm_schedule_items): which workgroup evaluates an item must not show in any result --
+    70 device-resident ticks (one re-pack inside) end bit-identical -- and the skipped steps are visible in the work count.
+    Against the plain run (no cutoff at all) the states agree to rounding: only terms below 2^-40 A are missing."""
+    sc, forces = scenarios.baseline_scenario("c2")
+    cfg = default_sfm_config(forces)
+    out = {}
+    for tag, env in (("dealt", {"SFM_CUTOFF": "2"}), ("natural", {"SFM_CUTOFF": "2", "SFM_SCHED": "0"}), ("plain", {"SFM_CUTOFF": "0"})):
+        for k in ("SFM_CUTOFF", "SFM_SCHED"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        eng = SfmEngine(cfg, 0.05)
+        try:
+            eng.upload_state(sc.loc, sc.vel, sc.waypoint, sc.target_speed, sc.radius, None)
+            eng.set_waypoint_stream(sc.seed, sc.world_side, 2.0)
+            eng.run(70, redraw=True)
+            out[tag] = (eng.state(), eng.pair_work())
+        finally:
+            eng.close()
+    for a, b in zip(out["dealt"][0], out["natural"][0]):
+        assert np.array_equal(a, b)
+    nominal = out["plain"][1][1]
+    assert out["dealt"][1][1] == out["natural"][1][1] < 0.9 * nominal          # the reach test skipped whole steps
+    for a, b in zip(out["dealt"][0][:2], out["plain"][0][:2]):
+        assert np.allclose(a, b, rtol=1e-5, atol=1e-5)

@@ -30,11 +30,7 @@ def measure(lo, hi):
     e.run(3, redraw=False)
     eng.synchronize()
     ms, t, l = e.timing()
-    try:
-        work = e.pair_work()[1]
-    except Exception:
-        work = 0
-    return ms / t * 1e3, l / t, work
+    return ms / t * 1e3, l / t, eng.work()
 
 
 t1 = None
