@@ -114,6 +114,7 @@ struct SfmHandle {
     int cut_mode = -1;                     // SFM_CUTOFF: 0 off, 1 list-based, 2 lite (+ dealt item order), -1 auto (list-based for N >= 8192)
     int sched_mode = -1;                   // SFM_SCHED=0: lite cutoff without the cost-balanced item order (A/B)
     unsigned long long* stamps = nullptr;  // SFM_STAMPS diagnostic: per-workgroup timestamps of the symmetric pair kernel
+    unsigned long long* geo_stamps = nullptr;   // SFM_GEO_STAMPS diagnostic: per-workgroup phase stamps of the geometry kernel
     // spatial reordering: row s holds the caller's pedestrian perm[s] (strips in x, each sorted by y: sfm_reorder.hip), so the 64-tiles
     // are compact squares; every download translates back.  Identity when off.
     std::vector<uint32_t> perm;
@@ -282,6 +283,10 @@ int sfm_create(const SfmParams* params, int device_id, SfmHandle** out) {
             if (f) fclose(f);
         }
     }
+    if (getenv("SFM_GEO_STAMPS")) {
+        if (hipMalloc(reinterpret_cast<void**>(&h->geo_stamps), sizeof(unsigned long long) * 4 * 8192) != hipSuccess) h->geo_stamps = nullptr;
+        else hipMemset(h->geo_stamps, 0, sizeof(unsigned long long) * 4 * 8192);
+    }
     h->dpp_dir = probe_dpp_direction(nullptr);
     *out = h;
     return SFM_OK;
@@ -307,6 +312,14 @@ int sfm_destroy(SfmHandle* h) {
             if (f) { for (size_t b = 0; b < 8192; ++b) fprintf(f, "%llu %llu %llu\n", st[3 * b], st[3 * b + 1], st[3 * b + 2]); fclose(f); }
         }
         hipFree(h->stamps);
+    }
+    if (h->geo_stamps && getenv("SFM_GEO_STAMPS")) {   // diagnostic: dump the last launch's per-workgroup phase stamps
+        std::vector<unsigned long long> st(4 * 8192);
+        if (hipMemcpy(st.data(), h->geo_stamps, sizeof(unsigned long long) * st.size(), hipMemcpyDeviceToHost) == hipSuccess) {
+            FILE* f = fopen(getenv("SFM_GEO_STAMPS"), "w");
+            if (f) { for (size_t b = 0; b < 8192; ++b) fprintf(f, "%llu %llu %llu %llu\n", st[4 * b], st[4 * b + 1], st[4 * b + 2], st[4 * b + 3]); fclose(f); }
+        }
+        hipFree(h->geo_stamps);
     }
     for (int b = 0; b < 2; ++b) { if (h->pk[b]) hipFree(h->pk[b]); if (h->zv[b]) hipFree(h->zv[b]); }
     if (h->own) hipFree(h->own);
@@ -427,8 +440,24 @@ int sfm_set_borders(SfmHandle* h, int K, const int32_t* offsets, const float* px
                 if (d > dev) dev = d;
             }
         }
+        // Straight and uniformly sampled (np.linspace between two points, obstacles.py:344-355)?  Then point j sits at
+        // a + (b - a) j / (P - 1); verified here point by point (2 % of the spacing), so the kernel may replace the scan
+        // over all P points by the few samples around the foot of the perpendicular (geo_item).  Curved or unevenly sampled
+        // polylines (the sidewalk borders of obstacles.py:72-166) fail the check and keep the full scan.
+        float n_seg = 0.f;
+        const int P = o1 - o0;
+        if (P >= 8 && !getenv("SFM_NO_STRAIGHT")) {
+            const double len = std::sqrt(abx * abx + aby * aby), spacing = len / (P - 1);
+            bool ok = spacing > 1e-6;
+            for (int j = 0; j < P && ok; ++j) {
+                const double ix = ax + abx * j / (P - 1), iy = ay + aby * j / (P - 1);
+                const double ex_ = px[o0 + j] - ix, ey_ = py[o0 + j] - iy;
+                ok = std::sqrt(ex_ * ex_ + ey_ * ey_) <= 0.02 * spacing;
+            }
+            if (ok) n_seg = (float)(P - 1);
+        }
         seg[2 * k] = make_float4((float)ax, (float)ay, (float)abx, (float)aby);
-        seg[2 * k + 1] = make_float4((float)inv, (float)(dev * 1.0001 + 1e-4), 0.f, 0.f);
+        seg[2 * k + 1] = make_float4((float)inv, (float)(dev * 1.0001 + 1e-4), n_seg, 0.f);
     }
     HIP_TRY(h, dev_realloc(h->borders.seg, (size_t)2 * K));
     HIP_TRY(h, hipMemcpy(h->borders.seg, seg.data(), sizeof(float4) * (size_t)2 * K, hipMemcpyHostToDevice));
@@ -791,6 +820,7 @@ static void fill_args(SfmHandle* h, TickArgs& a, uint32_t flags) {
     a.seed = h->seed;
     a.world_side = h->world_side;
     a.arrive_thr2 = (float)((double)h->arrive_thr * (double)h->arrive_thr);
+    a.geo_stamps = h->geo_stamps;
     a.borders = Geo{h->borders.off, h->borders.pts, h->borders.ctr, h->borders.seg, h->borders.K};
     a.statics = Geo{h->statics.off, h->statics.pts, h->statics.ctr, nullptr, h->statics.K};
     a.dynamics = Geo{h->dynamics.off, h->dynamics.pts, h->dynamics.ctr, nullptr, h->dynamics.K};

@@ -30,7 +30,8 @@ struct Geo {                  // CSR polylines / rings
     const int* off;           // [K+1]
     const float2* pts;        // [P] {x, y}
     const float4* ctr;        // [K] borders: {cx, cy, section_length^2, 0}; obstacles: {cx, cy, vx, vy}
-    const float4* seg;        // [2K] borders only: {ax, ay, abx, aby}, {1/|ab|^2, max deviation from segment ab, 0, 0}
+    const float4* seg;        // [2K] borders only: {ax, ay, abx, aby}, {1/|ab|^2, max deviation from segment ab, P-1 if the border is a
+                              // straight uniformly sampled line (verified on the host) else 0, 0}
     int K;
 };
 
@@ -104,6 +105,7 @@ struct TickArgs {
     float4* tile_box_out;     // lite cutoff: the epilogue writes the boxes / speeds of the NEXT tick's state here
     float* tile_vmax_out;
     FsmArgs fsm;
+    unsigned long long* geo_stamps;   // diagnostic runs only (SFM_GEO_STAMPS): per geometry workgroup {start, after find, after scan, end} of s_memrealtime
 };
 
 // Symmetric (antisymmetry-exploiting) pedestrian-force path, single shard only.

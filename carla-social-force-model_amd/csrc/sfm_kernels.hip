@@ -352,7 +352,32 @@ template <bool RAD>
 __device__ __forceinline__ void geo_item(const TickArgs& a, const GeoLane& me, const GeoItem& it, bool keep, float2* row,
                                          int lane, float (&f)[6]) {
     const Geo& g = it.kind == 0 ? a.borders : it.kind == 1 ? a.statics : a.dynamics;
-    const float2 sp = lane_nearest(g.pts, it.o0, it.o1, me.x, me.y, row, lane);
+    float2 sp;
+    if (it.kind == 0 && it.s1.z > 0.0f) {
+        // A border that sfm_set_borders verified to be a straight, uniformly sampled line (the config-defined borders of
+        // obstacles.py:344-355 are np.linspace between two points): the nearest SAMPLED point is the sample next to the foot of
+        // the perpendicular, so np.argmin's scan over all P points (forces.py:154) collapses to the five samples around it --
+        // evaluated with the same dist2, in ascending order with a strict `<` (first-minimum rule).  The samples either side of
+        // the optimum are > spacing^2 farther in d^2, far above the fp32 rounding of d^2 for any pedestrian that keeps the border.
+        sp = make_float2(3.0e15f, 3.0e15f);
+        if (keep) {
+            const float n_seg = it.s1.z;                                           // P - 1
+            const float px = me.x - it.s0.x, py = me.y - it.s0.y;
+            const float tt = fminf(fmaxf(fmaf(px, it.s0.z, py * it.s0.w) * it.s1.x, 0.0f), 1.0f);
+            const int k0 = (int)rintf(tt * n_seg);
+            const int lo = max(k0 - 2, 0), hi = min(k0 + 2, it.o1 - it.o0 - 1);
+            float bd = __builtin_inff();
+            for (int k = lo; k <= hi; ++k) {
+                const float2 q = g.pts[it.o0 + k];
+                const float d2 = dist2(me.x, me.y, q.x, q.y);
+                const bool take = d2 < bd;
+                bd = take ? d2 : bd;
+                sp = take ? q : sp;
+            }
+        }
+    } else {
+        sp = lane_nearest(g.pts, it.o0, it.o1, me.x, me.y, row, lane);
+    }
     if (!keep) return;
     if (it.kind == 0) {
         const float ddx = me.x - sp.x, ddy = me.y - sp.y;
@@ -440,6 +465,8 @@ __global__ __launch_bounds__(GEO_BLOCK) void sfm_geometry_kernel(const TickArgs 
     __shared__ int s_count[GEO_WAVES];
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = uniform((int)(threadIdx.x >> 6));
+    unsigned long long st0 = 0, st1 = 0, st2 = 0;
+    if (a.geo_stamps) st0 = __builtin_amdgcn_s_memrealtime();
     const int t = (a.i_begin >> 6) + blockIdx.x;                      // tile index
     const int p0 = max(a.i_begin, t * WAVE), p1 = min(a.i_end, (t + 1) * WAVE);
     const int i = t * WAVE + lane;
@@ -479,6 +506,7 @@ __global__ __launch_bounds__(GEO_BLOCK) void sfm_geometry_kernel(const TickArgs 
     const int n_found = geo_find<RAD, false>(a, me, tb, s_item[wave], row, lane, gwave, n_gwaves, f);
     if (lane == 0) s_count[wave] = min(n_found, GEO_ITEMS);
     __syncthreads();
+    if (a.geo_stamps) st1 = __builtin_amdgcn_s_memrealtime();
 
     // ---- phase 2: scan, items dealt round-robin in (wave, index) order
     {
@@ -502,6 +530,7 @@ __global__ __launch_bounds__(GEO_BLOCK) void sfm_geometry_kernel(const TickArgs 
 #pragma unroll
     for (int q = 0; q < 6; ++q) s_acc[wave][q][lane] = f[q];
     __syncthreads();
+    if (a.geo_stamps) st2 = __builtin_amdgcn_s_memrealtime();
     if (wave < 6 && me.live) {                                         // wave w finishes component w
         float v = 0.0f;
 #pragma unroll
@@ -509,6 +538,10 @@ __global__ __launch_bounds__(GEO_BLOCK) void sfm_geometry_kernel(const TickArgs 
         if (wave >= 4) v *= a.dyn.negA;
         else if (wave >= 2) v *= a.stat.negA;
         a.geo[((size_t)slice * 6 + wave) * a.N_pad + i] = v;
+    }
+    if (a.geo_stamps && threadIdx.x == 0) {
+        unsigned long long* o = a.geo_stamps + 4 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
+        o[0] = st0; o[1] = st1; o[2] = st2; o[3] = __builtin_amdgcn_s_memrealtime();
     }
 }
 
