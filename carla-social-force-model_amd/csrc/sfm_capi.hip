@@ -159,6 +159,10 @@ struct SfmHandle {
     hipStream_t aux = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool overlap_geo = true;
+    // sharded runs: the geometry forces of tick t+1 only need this rank's own rows of the new state, so they are launched on the
+    // side stream right after tick t's epilogue -- beside the all-gather the caller issues next -- and tick t+1 only joins them
+    bool geo_ahead = false;
+    int geo_ahead_mode = -1;               // SFM_GEO_AHEAD=0 switches it off
     int timed_ticks = 0, timed_launches = 0;
     bool timing_valid = false;
     int ipw_last = 0;
@@ -185,6 +189,15 @@ static int bind(SfmHandle* h) {
     hipError_t e = hipSetDevice(h->device);
     if (e != hipSuccess) { h->err = std::string("hipSetDevice: ") + hipGetErrorString(e); return SFM_ERR_HIP; }
     return SFM_OK;
+}
+
+// a geometry kernel launched ahead of its tick (SfmHandle::geo_ahead) reads state the caller is about to change: let it finish,
+// forget its result
+static void drop_geo_ahead(SfmHandle* h) {
+    if (h && h->geo_ahead) {
+        hipStreamSynchronize(h->aux);
+        h->geo_ahead = false;
+    }
 }
 
 template <typename T>
@@ -264,6 +277,8 @@ int sfm_create(const SfmParams* params, int device_id, SfmHandle** out) {
     if (ov) h->sym_mode = atoi(ov);
     ov = getenv("SFM_CUTOFF");
     if (ov) h->cut_mode = atoi(ov);
+    ov = getenv("SFM_GEO_AHEAD");
+    if (ov) h->geo_ahead_mode = atoi(ov);
     ov = getenv("SFM_SCHED");
     if (ov) h->sched_mode = atoi(ov);
     ov = getenv("SFM_REORDER");
@@ -362,6 +377,7 @@ int sfm_set_params(SfmHandle* h, const SfmParams* params) {
     if (!h) return SFM_ERR_INVALID;
     const char* why = nullptr;
     if (!check_params(params, &why)) return fail(h, SFM_ERR_INVALID, why);
+    drop_geo_ahead(h);
     h->prm = *params;
     return SFM_OK;
 }
@@ -378,6 +394,7 @@ static int set_geo(SfmHandle* h, DevGeo& g, int K, const int32_t* offsets, const
     int rc = bind(h);
     if (rc) return rc;
     if (K < 0) return fail(h, SFM_ERR_INVALID, "negative polyline count");
+    drop_geo_ahead(h);
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     if (K == 0) { free_geo(g); return SFM_OK; }
     if (!offsets) return fail(h, SFM_ERR_INVALID, "offsets is NULL");
@@ -538,6 +555,7 @@ int sfm_upload_state(SfmHandle* h, int N, const float* x, const float* y, const 
         return fail(h, SFM_ERR_INVALID, "a required state array is NULL");
     if ((z == nullptr) != (vz == nullptr)) return fail(h, SFM_ERR_INVALID, "z and vz must be given together");
     if (h->prm.use_ped_radius && N > 0 && !radius) return fail(h, SFM_ERR_INVALID, "use_ped_radius needs radius");
+    drop_geo_ahead(h);
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     const int n_pad = ((N + TILE_J - 1) / TILE_J) * TILE_J;
     const bool z3 = (z != nullptr);
@@ -674,6 +692,7 @@ int sfm_set_mode_fsm(SfmHandle* h, int N, const uint8_t* mode, const float* targ
                      int despawn_on_arrival, float sim_time0, const float* first_vehicle_extent) {
     int rc = bind(h);
     if (rc) return rc;
+    drop_geo_ahead(h);
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     if (N == 0) { h->fsm_on = false; return SFM_OK; }
     if (N != h->N) return fail(h, SFM_ERR_STATE, "sfm_set_mode_fsm: N differs from the uploaded state");
@@ -729,6 +748,7 @@ int sfm_download_modes(SfmHandle* h, uint8_t* mode, float* target_speed, int32_t
 int sfm_set_shard(SfmHandle* h, int i_begin, int i_end) {
     if (!h) return SFM_ERR_INVALID;
     if (i_begin < 0 || i_end < i_begin || i_end > h->N) return fail(h, SFM_ERR_INVALID, "shard out of range");
+    drop_geo_ahead(h);
     h->i_begin = i_begin;
     h->i_end = i_end;
     return SFM_OK;
@@ -829,6 +849,7 @@ static void fill_args(SfmHandle* h, TickArgs& a, uint32_t flags) {
 // Re-packs the rows spatially (strips in x, sorted by y: sfm_reorder.hip).  Whole-crowd handles only: a
 // shard's per-row data (waypoints, draw counters) of rows it does not own is not kept current.
 static int resort_rows(SfmHandle* h) {
+    drop_geo_ahead(h);
     const int N = h->N, np_ = h->N_pad;
     uint32_t* w = h->sort_buf;                     // 8 N_pad words: two 64-bit key arrays, two row arrays, two 32-bit key arrays
     ReorderBufs b{reinterpret_cast<unsigned long long*>(w), reinterpret_cast<unsigned long long*>(w + 2 * (size_t)np_),
@@ -934,8 +955,11 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags) {
             HIP_TRY(h, launch_tile_bounds(a.pk_cur, h->z3 ? a.zv_cur : nullptr, h->N, const_cast<float4*>(a.tile_box), const_cast<float*>(a.tile_vmax), h->stream));
             ++launches;
         }
+        const bool ahead = h->geo_ahead && a.geo && n_local > 0 && sym;   // launched at the end of the previous tick: join only
+        h->geo_ahead = false;
         const bool fork = a.geo && n_local > 0 && sym && h->overlap_geo;
-        if (fork) {
+        if (ahead) {
+        } else if (fork) {
             HIP_TRY(h, hipEventRecord(h->ev_fork, h->stream));
             HIP_TRY(h, hipStreamWaitEvent(h->aux, h->ev_fork, 0));
             HIP_TRY(h, launch_geometry(h->rad, a, h->aux));
@@ -972,6 +996,18 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags) {
             ++launches;
         }
         h->cur ^= 1;
+        // a shard's next geometry forces only need its own new rows: start them now, beside the exchange the caller issues next
+        if (sym && fork && !whole && (flags & SFM_TICK_INTEGRATE) && !h->fsm_on && h->geo_ahead_mode != 0 && t + 1 == ticks &&
+            !(flags & SFM_TICK_RECORD_FORCES)) {
+            TickArgs nx;
+            fill_args(h, nx, flags);
+            HIP_TRY(h, hipEventRecord(h->ev_fork, h->stream));
+            HIP_TRY(h, hipStreamWaitEvent(h->aux, h->ev_fork, 0));
+            HIP_TRY(h, launch_geometry(h->rad, nx, h->aux));
+            HIP_TRY(h, hipEventRecord(h->ev_join, h->aux));
+            h->geo_ahead = true;
+            ++launches;
+        }
         // lite cutoff: the epilogue left the next tick's boxes in the other buffer (valid only if this tick moved the crowd)
         if (lite && sym) { h->box_cur ^= 1; h->boxes_valid = (flags & SFM_TICK_INTEGRATE) != 0; }
         else h->boxes_valid = false;
