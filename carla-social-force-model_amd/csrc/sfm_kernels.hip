@@ -458,7 +458,7 @@ __device__ __forceinline__ int geo_find(const TickArgs& a, const GeoLane& me, co
 }
 
 template <bool RAD>
-__global__ __launch_bounds__(GEO_BLOCK) void sfm_geometry_kernel(const TickArgs a) {
+__global__ __launch_bounds__(GEO_BLOCK, 8) void sfm_geometry_kernel(const TickArgs a) {   // 8 waves per SIMD = 64 VGPRs: two workgroups per CU
     __shared__ float2 s_row[GEO_WAVES][WAVE];
     __shared__ float s_acc[GEO_WAVES][6][WAVE];
     __shared__ GeoItem s_item[GEO_WAVES][GEO_ITEMS];

@@ -14,6 +14,6 @@ for w in $wl; do
 done
 cd /tmp && export TMPDIR=/tmp
 for w in $wl; do
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_kt_$w -o k -- python3 $root/bench.py --workload $w --steps 300 --warmup 50 --no-cpu-baseline > $out/${tag}_kt_$w.log 2>&1 || exit 1
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_kt_$w -o k -- python3 $root/bench.py --workload $w --steps ${KT_STEPS:-300} --warmup 50 --no-cpu-baseline > $out/${tag}_kt_$w.log 2>&1 || exit 1
 done
 bash $root/tools/pmc_run.sh $tag $wl
