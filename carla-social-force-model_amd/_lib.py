@@ -80,6 +80,8 @@ SYMBOLS = {
     "sfm_profile_dominant_kernel": (C.c_int, [_H, C.c_int, C.POINTER(C.c_float)]),
     "sfm_kernel_variant": (C.c_char_p, [_H]),
     "sfm_get_pair_work": (C.c_int, [_H, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
+    "sfm_tick_begin": (C.c_int, [_H, C.c_uint32]),
+    "sfm_tick_end": (C.c_int, [_H, C.c_uint32]),
 }
 
 _lib = None

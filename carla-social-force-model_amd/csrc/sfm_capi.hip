@@ -17,7 +17,7 @@
 namespace sfm {
 hipError_t launch_tick(int ipw, int team, bool z3, bool rad, const TickArgs& a, hipStream_t st);
 hipError_t launch_arrived(const float4* pk, const float4* own, int N, float thr2, uint8_t* mask, hipStream_t st);
-hipError_t launch_sym_list(const TickArgs& a, const SymArgs& sa, hipStream_t st);
+hipError_t launch_sym_list(const TickArgs& a, const SymArgs& sa, hipStream_t st, int partners = 0);
 hipError_t launch_sym_pair(bool rad, const TickArgs& a, const SymArgs& sa, hipStream_t st);
 hipError_t launch_sym_epilogue(bool rad, const TickArgs& a, const SymArgs& sa, hipStream_t st);
 hipError_t launch_schedule(const int* cost, int n_t, uint32_t* work, int* count, hipStream_t st);
@@ -36,7 +36,8 @@ hipError_t launch_gather(const uint32_t* src, int N, const float4* pk_in, float4
                          const float4* own_in, float4* own_out, const float* rad_in, float* rad_out, const uint8_t* cr_in,
                          uint8_t* cr_out, const uint32_t* dr_in, uint32_t* dr_out, const uint32_t* id_in, uint32_t* id_out,
                          hipStream_t st);
-hipError_t launch_tile_bounds(const float4* pk, const float2* zv, int N, float4* box, float* vmax, hipStream_t st);
+hipError_t launch_tile_bounds(const float4* pk, const float2* zv, int N, float4* box, float* vmax, hipStream_t st, int t_lo = 0,
+                              int t_hi = -1);
 int probe_dpp_direction(hipStream_t st);
 hipError_t launch_dynamic_boxes(float4* ctr, const int* off, const float2* local, const float2* rot, float2* pts, int M,
                                 float dt, int advance, hipStream_t st);
@@ -163,6 +164,13 @@ struct SfmHandle {
     // side stream right after tick t's epilogue -- beside the all-gather the caller issues next -- and tick t+1 only joins them
     bool geo_ahead = false;
     int geo_ahead_mode = -1;               // SFM_GEO_AHEAD=0 switches it off
+    // split tick of a shard (sfm_tick_begin / sfm_tick_end): the own-own tile pairs are listed and evaluated before the other
+    // ranks' rows have arrived; their list lives in work2 / work_count[1]
+    uint32_t* work2 = nullptr;
+    size_t work2_cap = 0;
+    bool begin_done = false, begin_forked = false, last_split = false;
+    uint32_t begin_flags = 0;
+    int split_mode = -1;                   // SFM_SPLIT=0: sfm_tick_begin never does anything (A/B, tests)
     int timed_ticks = 0, timed_launches = 0;
     bool timing_valid = false;
     int ipw_last = 0;
@@ -198,6 +206,7 @@ static void drop_geo_ahead(SfmHandle* h) {
         hipStreamSynchronize(h->aux);
         h->geo_ahead = false;
     }
+    if (h) h->begin_done = false;          // (a half-done split tick is simply redone in full)
 }
 
 template <typename T>
@@ -277,6 +286,8 @@ int sfm_create(const SfmParams* params, int device_id, SfmHandle** out) {
     if (ov) h->sym_mode = atoi(ov);
     ov = getenv("SFM_CUTOFF");
     if (ov) h->cut_mode = atoi(ov);
+    ov = getenv("SFM_SPLIT");
+    if (ov) h->split_mode = atoi(ov);
     ov = getenv("SFM_GEO_AHEAD");
     if (ov) h->geo_ahead_mode = atoi(ov);
     ov = getenv("SFM_SCHED");
@@ -363,6 +374,7 @@ int sfm_destroy(SfmHandle* h) {
     if (h->work) hipFree(h->work);
     if (h->work_count) hipFree(h->work_count);
     if (h->cost) hipFree(h->cost);
+    if (h->work2) hipFree(h->work2);
     free_geo(h->borders); free_geo(h->statics); free_geo(h->dynamics);
     if (h->aux) { hipStreamSynchronize(h->aux); hipStreamDestroy(h->aux); }
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
@@ -679,7 +691,8 @@ int sfm_upload_state(SfmHandle* h, int N, const float* x, const float* y, const 
     {
         const size_t items = (size_t)h->n_t * (size_t)(h->n_t / 2 + 1);
         if (h->n_t < 65536 && items > h->work_cap) { HIP_TRY(h, dev_realloc(h->work, items)); h->work_cap = items; }
-        if (!h->work_count) HIP_TRY(h, dev_realloc(h->work_count, (size_t)1));
+        if (!h->work_count) HIP_TRY(h, dev_realloc(h->work_count, (size_t)2));
+        h->begin_done = false;
         if (h->n_t <= 128 && items > h->cost_cap) { HIP_TRY(h, dev_realloc(h->cost, items)); h->cost_cap = items; }
         h->sched_valid = false;
     }
@@ -897,11 +910,15 @@ static SymArgs make_sym_args(const SfmHandle* h, const TickArgs& a, int tps, int
                    h->i_begin / WAVE, (h->i_end + WAVE - 1) / WAVE, sched ? h->cost : nullptr, -1};
 }
 
-static int run_ticks(SfmHandle* h, int ticks, uint32_t flags) {
+constexpr int PHASE_FULL = 0, PHASE_BEGIN = 1, PHASE_END = 2;
+constexpr int LIST_ALL = 0, LIST_OWN = 1, LIST_REMOTE = 2;        // = PARTNERS_* of sfm_kernels.hip
+
+static int run_ticks(SfmHandle* h, int ticks, uint32_t flags, int phase = PHASE_FULL) {
     int rc = bind(h);
     if (rc) return rc;
     if (ticks < 0) return fail(h, SFM_ERR_INVALID, "ticks < 0");
-    h->timing_valid = false;
+    if (phase == PHASE_END && h->begin_done) flags = h->begin_flags;
+    if (phase != PHASE_END) h->timing_valid = false;
     if (h->N == 0 || ticks == 0) return SFM_OK;        // tick() early-out (pedestrian_simulation.py:60-61)
     if (!h->pk[0]) return fail(h, SFM_ERR_STATE, "sfm_upload_state has not been called");
     const int n_local = h->i_end - h->i_begin;
@@ -931,8 +948,45 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags) {
     if (sym) snprintf(h->variant, sizeof(h->variant), "sfm_pair_sym_kernel+sfm_sym_epilogue_kernel");
     else snprintf(h->variant, sizeof(h->variant), "sfm_tick_kernel<%d,%s,%s,%d>", ipw, h->z3 ? "true" : "false",
                   h->rad ? "true" : "false", team);
-    HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
-    int launches = 0;
+    // ---- split tick of a shard: what needs only this rank's rows first (sfm_tick_begin), the rest once the exchange is in
+    //      (sfm_tick_end).  Anything else: sfm_tick_begin does nothing and sfm_tick_end runs the whole tick.
+    if (phase == PHASE_BEGIN) {
+        h->begin_done = false;
+        if (!(sym && !whole && list_cut && !h->fsm_on && (flags & SFM_TICK_INTEGRATE) && n_local > 0 && h->split_mode != 0)) return SFM_OK;
+        const size_t items = (size_t)h->n_t * (size_t)(h->n_t / 2 + 1);
+        if (items > h->work2_cap) { HIP_TRY(h, dev_realloc(h->work2, items)); h->work2_cap = items; }
+        HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+        ++h->ticks_since_sort;
+        TickArgs a;
+        fill_args(h, a, flags);
+        const int t_lo = h->i_begin / WAVE, t_hi = (h->i_end + WAVE - 1) / WAVE;
+        HIP_TRY(h, launch_tile_bounds(a.pk_cur, nullptr, h->N, const_cast<float4*>(a.tile_box), const_cast<float*>(a.tile_vmax), h->stream,
+                                      t_lo, t_hi));
+        const bool ahead = h->geo_ahead && a.geo;
+        h->geo_ahead = false;
+        h->begin_forked = a.geo != nullptr;
+        if (a.geo && !ahead) {
+            HIP_TRY(h, hipEventRecord(h->ev_fork, h->stream));
+            HIP_TRY(h, hipStreamWaitEvent(h->aux, h->ev_fork, 0));
+            HIP_TRY(h, launch_geometry(h->rad, a, h->aux));
+            HIP_TRY(h, hipEventRecord(h->ev_join, h->aux));
+        }
+        SymArgs sa = make_sym_args(h, a, tps, 0, h->debug_steps, nullptr);
+        sa.work = h->work2;
+        sa.work_count = h->work_count + 1;
+        HIP_TRY(h, launch_sym_list(a, sa, h->stream, LIST_OWN));
+        HIP_TRY(h, launch_sym_pair(h->rad, a, sa, h->stream));
+        h->begin_done = true;
+        h->begin_flags = flags;
+        h->timed_launches = 3 + (a.geo && !ahead ? 1 : 0);
+        return SFM_OK;
+    }
+    const bool finishing = phase == PHASE_END && h->begin_done;   // the own-own pairs of this tick are already in the slab
+    if (finishing) snprintf(h->variant, sizeof(h->variant), "sfm_pair_sym_kernel(own|remote)+sfm_sym_epilogue_kernel");
+    h->begin_done = false;
+    h->last_split = finishing;
+    if (!finishing) HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+    int launches = finishing ? h->timed_launches : 0;
     for (int t = 0; t < ticks; ++t) {
         if (h->reordered && h->resort_every > 0 && (flags & SFM_TICK_INTEGRATE) && h->i_begin == 0 && h->i_end == h->N &&
             h->ticks_since_sort >= h->resort_every && order_pays) {
@@ -940,7 +994,7 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags) {
             if (rc) return rc;
             launches += 5;
         }
-        ++h->ticks_since_sort;
+        if (!finishing) ++h->ticks_since_sort;
         TickArgs a;
         fill_args(h, a, flags);
         // border / obstacle forces only need the tick's input state.  With the symmetric path they run on the side
@@ -955,9 +1009,10 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags) {
             HIP_TRY(h, launch_tile_bounds(a.pk_cur, h->z3 ? a.zv_cur : nullptr, h->N, const_cast<float4*>(a.tile_box), const_cast<float*>(a.tile_vmax), h->stream));
             ++launches;
         }
-        const bool ahead = h->geo_ahead && a.geo && n_local > 0 && sym;   // launched at the end of the previous tick: join only
+        const bool ahead = (h->geo_ahead && a.geo && n_local > 0 && sym) ||   // launched at the end of the previous tick ...
+                           (finishing && h->begin_forked);                     // ... or by sfm_tick_begin: join only
         h->geo_ahead = false;
-        const bool fork = a.geo && n_local > 0 && sym && h->overlap_geo;
+        const bool fork = a.geo && n_local > 0 && sym && (h->overlap_geo || finishing);
         if (ahead) {
         } else if (fork) {
             HIP_TRY(h, hipEventRecord(h->ev_fork, h->stream));
@@ -984,7 +1039,7 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags) {
                 ++launches;
             }
             if (sa.work && !sa.cost) {
-                HIP_TRY(h, launch_sym_list(a, sa, h->stream));
+                HIP_TRY(h, launch_sym_list(a, sa, h->stream, finishing ? LIST_REMOTE : LIST_ALL));
                 ++launches;
             }
             HIP_TRY(h, launch_sym_pair(h->rad, a, sa, h->stream));
@@ -1063,6 +1118,10 @@ int sfm_profile_dominant_kernel(SfmHandle* h, int reps, float* avg_us) {
 }
 
 int sfm_tick(SfmHandle* h, uint32_t flags) { return run_ticks(h, 1, flags); }
+
+int sfm_tick_begin(SfmHandle* h, uint32_t flags) { return run_ticks(h, 1, flags | SFM_TICK_INTEGRATE, PHASE_BEGIN); }
+
+int sfm_tick_end(SfmHandle* h, uint32_t flags) { return run_ticks(h, 1, flags | SFM_TICK_INTEGRATE, PHASE_END); }
 
 int sfm_run(SfmHandle* h, int ticks, uint32_t flags) { return run_ticks(h, ticks, flags | SFM_TICK_INTEGRATE); }
 
@@ -1297,9 +1356,9 @@ int sfm_get_pair_work(SfmHandle* h, long long* tile_pair_items, long long* pair_
         return SFM_OK;
     }
     if (h->last_list) {
-        int cnt = 0;
-        HIP_TRY(h, hipMemcpy(&cnt, h->work_count, sizeof(int), hipMemcpyDeviceToHost));
-        items = cnt;
+        int cnt[2] = {0, 0};
+        HIP_TRY(h, hipMemcpy(cnt, h->work_count, sizeof(int) * 2, hipMemcpyDeviceToHost));
+        items = cnt[0] + (h->last_split ? cnt[1] : 0);          // split tick: the own-own items were listed separately
     } else {                                       // 2-D grid: every unordered tile pair once + the diagonal items
         const long long n_t = h->n_t;
         items = n_t * (n_t - 1) / 2 + diag_items;

@@ -1002,8 +1002,8 @@ __global__ __launch_bounds__(BLOCK) void sfm_tick_kernel(const TickArgs a) {
 }
 
 __global__ __launch_bounds__(WAVE) void sfm_tile_bounds_kernel(const float4* __restrict__ pk, const float2* __restrict__ zv, int N,
-                                                               float4* __restrict__ box, float* __restrict__ vmax) {
-    const int t = blockIdx.x, lane = threadIdx.x;
+                                                               float4* __restrict__ box, float* __restrict__ vmax, int t0) {
+    const int t = t0 + blockIdx.x, lane = threadIdx.x;
     const int i = t * WAVE + lane;
     const float inf = __builtin_inff();
     float x0 = inf, y0 = inf, x1 = -inf, y1 = -inf, v = 0.0f;
@@ -1054,20 +1054,24 @@ __global__ __launch_bounds__(WAVE) void sfm_strip_bounds_kernel(const float4* __
 // grid); a pair with a tile of another rank is kept by both ranks, each evaluating its own side only (bit 31).
 // Diagonal items (shift 0) are always kept and carry two diagonal tiles each.
 constexpr uint32_t WORK_ONE_SIDED = 0x80000000u;
+// `partners`: PARTNERS_ALL, or only the items whose two tiles are both own (PARTNERS_OWN: what a shard can evaluate before the
+// other ranks' rows have arrived), or only the others (PARTNERS_REMOTE).
+constexpr int PARTNERS_ALL [[maybe_unused]] = 0, PARTNERS_OWN = 1, PARTNERS_REMOTE = 2;
 __global__ void sfm_pair_list_kernel(const float4* __restrict__ box, const float* __restrict__ vmax, int n_t, int t_lo, int t_hi,
                                      float lam, float cut_scale, float cut_pad, uint32_t* __restrict__ work,
-                                     int* __restrict__ count) {
+                                     int* __restrict__ count, int partners) {
     const int bx = t_lo + blockIdx.x * blockDim.x + threadIdx.x;
     const int shift = blockIdx.y;
     if (bx >= t_hi) return;
     bool keep;
     uint32_t one = 0u;
     if (shift == 0) {
-        keep = (bx - t_lo) < ((t_hi - t_lo + 1) >> 1);
+        keep = (bx - t_lo) < ((t_hi - t_lo + 1) >> 1) && partners != PARTNERS_REMOTE;
     } else {
         int tb = bx + shift;
         if (tb >= n_t) tb -= n_t;
         const bool own = tb >= t_lo && tb < t_hi;
+        if ((partners == PARTNERS_OWN && !own) || (partners == PARTNERS_REMOTE && own)) return;
         if (own) keep = shift <= (n_t >> 1) && !(!(n_t & 1) && shift == (n_t >> 1) && bx >= (n_t >> 1));
         else { keep = true; one = WORK_ONE_SIDED; }
         if (keep) keep = !tiles_negligible(box[bx], vmax[bx], box[tb], vmax[tb], lam, cut_scale, cut_pad);
@@ -1080,7 +1084,7 @@ __global__ void sfm_pair_list_kernel(const float4* __restrict__ box, const float
 // holds only negligible tiles -- the result is exactly the flat kernel's), then the tiles of the surviving strips.
 __global__ __launch_bounds__(BLOCK) void sfm_pair_list2_kernel(const float4* __restrict__ box, const float* __restrict__ vmax,
                                                                const SymArgs sa, float lam, uint32_t* __restrict__ work,
-                                                               int* __restrict__ count) {
+                                                               int* __restrict__ count, int partners) {
     constexpr int BUF = 256;                              // a wave collects its items in LDS: one atomic per flush
     __shared__ uint32_t s_item[WAVES_PER_BLOCK][BUF];
     const int lane = threadIdx.x & (WAVE - 1);
@@ -1135,10 +1139,11 @@ __global__ __launch_bounds__(BLOCK) void sfm_pair_list2_kernel(const float4* __r
                 int shift = tb - bx;
                 if (shift < 0) shift += n_t;
                 if (shift == 0) {
-                    keep = (bx - sa.t_lo) < ((sa.t_hi - sa.t_lo + 1) >> 1);
+                    keep = (bx - sa.t_lo) < ((sa.t_hi - sa.t_lo + 1) >> 1) && partners != PARTNERS_REMOTE;
                 } else {
                     const bool own = tb >= sa.t_lo && tb < sa.t_hi;
-                    if (own) keep = shift <= (n_t >> 1) && !(!(n_t & 1) && shift == (n_t >> 1) && bx >= (n_t >> 1));
+                    if ((partners == PARTNERS_OWN && !own) || (partners == PARTNERS_REMOTE && own)) keep = false;
+                    else if (own) keep = shift <= (n_t >> 1) && !(!(n_t & 1) && shift == (n_t >> 1) && bx >= (n_t >> 1));
                     if (keep) keep = !tiles_negligible(bt, vt, cb, cv, lam, sa.cut_scale, sa.cut_pad);
                     item = own ? 0u : WORK_ONE_SIDED;
                 }
@@ -1689,18 +1694,20 @@ hipError_t launch_geometry(bool rad, const TickArgs& a, hipStream_t st) {
 }
 
 // cutoff on: compact the tile pairs that have to be evaluated (the work list of the pair kernel)
-hipError_t launch_sym_list(const TickArgs& a, const SymArgs& sa, hipStream_t st) {
+hipError_t launch_sym_list(const TickArgs& a, const SymArgs& sa, hipStream_t st, int partners = PARTNERS_ALL) {
     if (a.N <= 1 || !a.en_ped || !sa.work || sa.cost) return hipSuccess;       // (scheduled mode: the order is dealt, not built)
     hipError_t e = hipMemsetAsync(const_cast<int*>(sa.work_count), 0, sizeof(int), st);
     if (e != hipSuccess) return e;
     const bool whole = sa.t_lo == 0 && sa.t_hi == sa.n_t;      // a shard also looks at partners behind it
-    if (sa.n_strips > 0)
+    // own partners only (PARTNERS_OWN): the strips' boxes need every tile's box, which a shard does not have yet -- flat kernel
+    if (sa.n_strips > 0 && partners != PARTNERS_OWN)
         hipLaunchKernelGGL(sfm_pair_list2_kernel, dim3((sa.t_hi - sa.t_lo + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), dim3(BLOCK), 0, st,
-                           a.tile_box, a.tile_vmax, sa, a.ped.lam, const_cast<uint32_t*>(sa.work), const_cast<int*>(sa.work_count));
+                           a.tile_box, a.tile_vmax, sa, a.ped.lam, const_cast<uint32_t*>(sa.work), const_cast<int*>(sa.work_count),
+                           partners);
     else
         hipLaunchKernelGGL(sfm_pair_list_kernel, dim3((sa.t_hi - sa.t_lo + 255) / 256, whole ? sa.n_t / 2 + 1 : sa.n_t), dim3(256), 0, st,
                            a.tile_box, a.tile_vmax, sa.n_t, sa.t_lo, sa.t_hi, a.ped.lam, a.cut_scale, a.cut_pad,
-                           const_cast<uint32_t*>(sa.work), const_cast<int*>(sa.work_count));
+                           const_cast<uint32_t*>(sa.work), const_cast<int*>(sa.work_count), partners);
     return hipGetLastError();
 }
 
@@ -1728,9 +1735,12 @@ hipError_t launch_sym_pair(bool rad, const TickArgs& a, const SymArgs& sa, hipSt
     return hipGetLastError();
 }
 
-hipError_t launch_tile_bounds(const float4* pk, const float2* zv, int N, float4* box, float* vmax, hipStream_t st) {
+hipError_t launch_tile_bounds(const float4* pk, const float2* zv, int N, float4* box, float* vmax, hipStream_t st, int t_lo = 0,
+                              int t_hi = -1) {
     if (N <= 0) return hipSuccess;
-    hipLaunchKernelGGL(sfm_tile_bounds_kernel, dim3((N + WAVE - 1) / WAVE), dim3(WAVE), 0, st, pk, zv, N, box, vmax);
+    if (t_hi < 0) t_hi = (N + WAVE - 1) / WAVE;                 // default: every tile
+    if (t_hi <= t_lo) return hipSuccess;
+    hipLaunchKernelGGL(sfm_tile_bounds_kernel, dim3(t_hi - t_lo), dim3(WAVE), 0, st, pk, zv, N, box, vmax, t_lo);
     return hipGetLastError();
 }
 

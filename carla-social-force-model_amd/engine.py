@@ -251,6 +251,14 @@ class SfmEngine:
     def run(self, ticks, redraw=False, record=False):
         self._check(self._lib.sfm_run(self._h, int(ticks), self._flags(True, redraw, record)), "sfm_run")
 
+    def tick_begin(self, redraw=False):
+        """First half of an integrating tick of a shard: everything that only needs this handle's own rows (sfm_tick_begin)."""
+        self._check(self._lib.sfm_tick_begin(self._h, self._flags(True, redraw, False)), "sfm_tick_begin")
+
+    def tick_end(self, redraw=False):
+        """Second half, once the other ranks' rows are current (sfm_tick_end)."""
+        self._check(self._lib.sfm_tick_end(self._h, self._flags(True, redraw, False)), "sfm_tick_end")
+
     def run_recorded(self, ticks, stride=1, redraw=False):
         """``run`` that records {x, y, vx, vy} of every pedestrian before tick 0, stride, 2*stride, ...
         Returns (frames[F, N, 4] float32, tick_index[F])."""

@@ -117,6 +117,14 @@ class HipShardEngine:
     def run(self, ticks, redraw=True):
         self.engine.run(ticks, redraw=redraw)
 
+    def begin(self, redraw=True):
+        """The part of the next tick that only reads this rank's own rows (runs beside the exchange of the previous tick)."""
+        self.engine.tick_begin(redraw=redraw)
+
+    def end(self, redraw=True):
+        """The rest of the tick; every other rank's rows must be current."""
+        self.engine.tick_end(redraw=redraw)
+
     def _view(self, ptr, width):
         key = (ptr, width)
         if key not in self._views:
@@ -206,26 +214,40 @@ class ShardedStepper:
         self._gather(self.engine.packed())
 
     def _gather(self, buffers):
+        self._gather_finish(self._gather_start(buffers))
+
+    def _gather_start(self, buffers):
         """Every rank's own rows of each buffer reach every other rank.  Equal shares: ONE in-place
         all_gather_into_tensor on the buffer itself.  Unequal shares (balanced boundaries): the own rows go into this
         rank's slot of a staging tensor padded to the largest share, one in-place all_gather_into_tensor on it, and one
-        indexed copy spreads the other ranks' rows over the buffer (two small kernels beside the collective)."""
+        indexed copy spreads the other ranks' rows over the buffer (two small kernels beside the collective).
+        The collectives are issued asynchronously; ``_gather_finish`` waits for them (and does the indexed copies), so
+        work that only touches this rank's own rows can be queued in between."""
         import torch.distributed as dist
         b = self.bounds
         sizes = [b[r + 1] - b[r] for r in range(self.world)]
         chunk = sizes[0]
         even = all(sz == chunk for sz in sizes[:-1]) and sizes[-1] <= chunk and all(b[r] == r * chunk for r in range(self.world))
+        pending = []
         for buf, width in buffers:
             if even and buf.numel() >= self.world * chunk * width:
                 mine = buf[self.rank * chunk * width:(self.rank + 1) * chunk * width]
-                dist.all_gather_into_tensor(buf[:self.world * chunk * width], mine, group=self.group)
+                w = dist.all_gather_into_tensor(buf[:self.world * chunk * width], mine, group=self.group, async_op=True)
+                pending.append((w, None))
                 continue
             stage, src, dst = self._plan(buf, width, sizes)
             rows = buf.view(-1, width)
-            cmax = stage.shape[1]
             stage[self.rank, :sizes[self.rank]].copy_(rows[self.lo:self.hi])
-            dist.all_gather_into_tensor(stage.view(-1), stage[self.rank].reshape(-1), group=self.group)
-            rows.index_copy_(0, dst, stage.view(self.world * cmax, width).index_select(0, src))
+            w = dist.all_gather_into_tensor(stage.view(-1), stage[self.rank].reshape(-1), group=self.group, async_op=True)
+            pending.append((w, (rows, stage, src, dst, width)))
+        return pending
+
+    def _gather_finish(self, pending):
+        for w, unpack in pending or ():
+            w.wait()
+            if unpack is not None:
+                rows, stage, src, dst, width = unpack
+                rows.index_copy_(0, dst, stage.view(-1, width).index_select(0, src))
 
     def _plan(self, buf, width, sizes):
         """(staging tensor [world, largest share, width], source rows in it, destination rows in the buffer) for the
@@ -275,16 +297,31 @@ class ShardedStepper:
         self.engine.set_shard(self.lo, self.hi)
 
     def step(self, ticks=1):
+        """``ticks`` ticks.  Sharded: the exchange of tick t's rows is started right after tick t and only waited for
+        after the part of tick t+1 that reads nothing but this rank's own rows (``engine.begin``: tile boxes, border /
+        obstacle forces, own-own tile pairs) has been queued -- the collective runs beside it.
+        On return the exchange of the last tick has completed: every rank holds the whole state."""
         driver_resorts = self.resort_every > 0 and not (self.world == 1 and getattr(self.engine, "auto_resort", False))
         if self.world == 1 and not driver_resorts:
             self.engine.run(ticks, redraw=self.redraw)      # no exchange needed: launch back to back
         else:
+            split = self.world > 1 and hasattr(self.engine, "begin")
+            pending = None
             for _ in range(ticks):
                 if driver_resorts and self.since_resort >= self.resort_every:
+                    self._gather_finish(pending)
+                    pending = None
                     self._repack()
-                self.engine.run(1, redraw=self.redraw)
-                self.exchange()
+                if split:
+                    self.engine.begin(redraw=self.redraw)
+                    self._gather_finish(pending)
+                    self.engine.end(redraw=self.redraw)
+                else:
+                    self._gather_finish(pending)
+                    self.engine.run(1, redraw=self.redraw)
+                pending = self._gather_start(self.engine.packed()) if self.world > 1 else None
                 self.since_resort += 1
+            self._gather_finish(pending)
         self.ticks_done += ticks
 
     def local_rows(self):

@@ -158,6 +158,15 @@ int sfm_tick(SfmHandle* h, uint32_t flags);
 /* `ticks` ticks back to back without host intervention (device-resident loop for benchmarks and the
  * CARLA-free harness); flags as above, SFM_TICK_INTEGRATE is implied. */
 int sfm_run(SfmHandle* h, int ticks, uint32_t flags);
+/* One integrating tick of a SHARD in two halves, so that the exchange of the previous tick's rows (the one all-gather per tick
+ * of SURVEY.md section 8e; no reference counterpart, the reference is single-process) can run beside the part that does not
+ * need it.  sfm_tick_begin: what only reads this handle's own rows -- their tile boxes, the border / obstacle forces, the tile
+ * pairs whose two tiles are both own.  sfm_tick_end: once every other rank's rows are current in the packed state -- the pairs
+ * with the other ranks' tiles, the epilogue (pedestrian_simulation.py:81-83, :117-124).  Results are those of sfm_tick with
+ * SFM_TICK_INTEGRATE (bit-identical: the same terms reach the same slab rows).  When the handle is not a tile-aligned shard
+ * on the symmetric path with the tile-pair list, sfm_tick_begin does nothing and sfm_tick_end runs the whole tick. */
+int sfm_tick_begin(SfmHandle* h, uint32_t flags);
+int sfm_tick_end(SfmHandle* h, uint32_t flags);
 
 /* sfm_run that also records the trajectory (replaces the per-tick full-state Python
  * copy of PedState.record_current_state, pedestrian_state.py:100-104): frame f holds {x, y, vx, vy} of every

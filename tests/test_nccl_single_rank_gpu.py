@@ -93,7 +93,7 @@ def test_row_shards_reassemble_the_full_tick():
         os.environ.pop("SFM_SYM", None)
 
 
-@pytest.mark.parametrize("path", ["ordered", "symmetric"])
+@pytest.mark.parametrize("path", ["ordered", "symmetric", "symmetric-split"])
 def test_two_shards_with_row_repacking_match_the_whole_crowd_run(path, monkeypatch):
     """What two ranks do, replayed on one GPU with two handles: a tick on the own rows, the exchange of the packed
     records (here a device copy instead of the all-gather), and every 4 ticks the re-pack protocol of
@@ -103,6 +103,11 @@ def test_two_shards_with_row_repacking_match_the_whole_crowd_run(path, monkeypat
     from carla_social_force_model_amd.stepper import HipShardEngine, shard_bounds
     # ordered kernel on every handle: bit-identical.  Symmetric kernel (tile-aligned shards + tile-pair list): a pair
     # across the shard boundary is evaluated one-sided by both handles, so sums are ordered differently -> rounding only.
+    # "symmetric-split": the tick in two halves (sfm_tick_begin / sfm_tick_end) with the exchange of the PREVIOUS tick's rows in
+    # between -- what ShardedStepper.step does to run the collective beside the own-own tile pairs.
+    split = path == "symmetric-split"
+    if split:
+        path = "symmetric"
     env = {"SFM_CUTOFF": "1", "SFM_RESORT_EVERY": "4"}
     env.update({"SFM_SYM": "0", "SFM_IPW": "4", "SFM_TEAM": "1"} if path == "ordered" else {"SFM_SYM": "1"})
     for k, v in env.items():
@@ -144,10 +149,20 @@ def test_two_shards_with_row_repacking_match_the_whole_crowd_run(path, monkeypat
                 e.resort()
             after = ranks[0].engine.state()[0]
             moved += int((np.isnan(before[:, 0]) != np.isnan(after[:, 0])).sum())   # pedestrians that changed rank
-        for e in ranks:
-            e.run(1)
-            e.synchronize()
-        exchange(lambda e: e.packed())
+        if split:
+            for e in ranks:
+                e.begin()                                  # own rows only: the other handle's rows are still one tick old here
+            exchange(lambda e: e.packed())
+            for e in ranks:
+                e.end()
+                e.synchronize()
+            if (t + 1) % 4 == 0 or t + 1 == ticks:         # the re-pack (and the final comparison) needs the whole state
+                exchange(lambda e: e.packed())
+        else:
+            for e in ranks:
+                e.run(1)
+                e.synchronize()
+            exchange(lambda e: e.packed())
     assert moved > 0
     got = [e.engine.state() for e in ranks]
     for k in range(3):
@@ -159,6 +174,7 @@ def test_two_shards_with_row_repacking_match_the_whole_crowd_run(path, monkeypat
         else:
             assert np.allclose(merged, ref[k], rtol=2e-5, atol=2e-5)
     assert all(("sym" in e.engine.kernel_variant()) == (path == "symmetric") for e in ranks)
+    assert all(("own|remote" in e.engine.kernel_variant()) == split for e in ranks)      # the split tick really ran in two halves
     for e in ranks:
         e.close()
 
