@@ -139,14 +139,20 @@ __device__ __forceinline__ void moussaid(const IxConst& c, float dx, float dy, f
 //   C = t . (dx,dy) = d cos, and the half-angle ratio is S / (d + |C|).
 // d2 is NOT padded: a coincident pair gives rsq(0) = inf -> d = NaN -> a NaN term, which the epilogue takes as the
 // signal to recompute the tile with the exact body (the reference's conventions for zero vectors, forces.py:97,105).
-template <bool RAD>
-__device__ __forceinline__ void moussaid_planar(const IxConst& c, float dx, float dy, float d2, float wx, float wy, float rsum,
+// CUT: once -d/B is known (two of the five transcendentals in), a step whose 64 exponents are ALL below -41 is dropped: both
+// exponentials of every lane are then < 2^-41, the term < 2^-40 A (the same policy as the tile and the reach tests, now with the
+// pair's actual |D| instead of a speed bound).  A NaN exponent (coincident pair) never counts as small.  Returns false if dropped.
+template <bool RAD, bool CUT>
+__device__ __forceinline__ bool moussaid_planar(const IxConst& c, float dx, float dy, float d2, float wx, float wy, float rsum,
                                                 float& cx, float& cy) {
     const float rinv = rsq(d2);
     const float d = d2 * rinv;
     const float Dx = fmaf(dx, rinv, wx), Dy = fmaf(dy, rinv, wy);
     const float D2 = fmaf(Dx, Dx, fmaf(Dy, Dy, TINY));
     const float rD = rsq(D2);
+    const float deff = RAD ? d - rsum : d;
+    const float aL = deff * (rD * c.c1);
+    if (CUT && !__any(!(aL <= -41.0f))) return false;
     const float Dn = D2 * rD;                                          // |D|
     const float tx = Dx * rD, ty = Dy * rD;
     const float S = fmaf(tx, dy, -(ty * dx));                          // d sin(angle(e) - angle(t))
@@ -166,13 +172,12 @@ __device__ __forceinline__ void moussaid_planar(const IxConst& c, float dx, floa
     const float theta = fmaf(-c.eg, Dn, ang);                          // forces.py:101
     const float q = Dn * theta;
     const float q2 = q * q;
-    const float deff = RAD ? d - rsum : d;
-    const float aL = deff * (rD * c.c1);
     const float e1 = ex2(fmaf(q2, c.k1, aL));
     const float e2 = ex2(fmaf(q2, c.k2, aL));
     const float g = copysignf(e2, theta);
     cx = fmaf(e1, tx, -(g * ty));
     cy = fmaf(e1, ty, g * tx);
+    return true;
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -1267,11 +1272,12 @@ __global__ __launch_bounds__(BLOCK) void sfm_pair_sym_kernel(const float4* __res
             const float d2 = fmaf(dx, dx, dy * dy);
             if (!CUT || __any(!(d2 > reach2))) {
                 float cx, cy;
-                moussaid_planar<RAD>(c, dx, dy, d2, uxi - ujx, uyi - ujy, RAD ? ri + rj : 0.f, cx, cy);
-                fxi += cx;
-                fyi += cy;
-                if (both) { fxj -= cx; fyj -= cy; }
-                ++executed;
+                if (moussaid_planar<RAD, CUT>(c, dx, dy, d2, uxi - ujx, uyi - ujy, RAD ? ri + rj : 0.f, cx, cy)) {
+                    fxi += cx;
+                    fyi += cy;
+                    if (both) { fxj -= cx; fyj -= cy; }
+                    ++executed;
+                }
             }
             xi = rot1(xi); yi = rot1(yi); uxi = rot1(uxi); uyi = rot1(uyi);
             if (RAD) ri = rot1(ri);
