@@ -1365,11 +1365,21 @@ __device__ void sfm_schedule_items(const int* __restrict__ cost, int n_t, uint32
     for (int id = tid; id < n_slots; id += nthreads)
         if (active(id)) atomicAdd(&s_hist[64 - min(max(cost[id], 0), 64)], 1);      // bucket 0 = the most expensive
     __syncthreads();
-    if (tid == 0) {
-        int run = 0;
-        for (int q = 0; q < 65; ++q) { const int c = s_hist[q]; s_hist[q] = run; run += c; }
-        s_hist[65] = run;                                                            // number of items
-        *count = run;
+    if (tid < WAVE) {                                                                // exclusive prefix over the 65 buckets: one wave
+        const int v = s_hist[tid];
+        int incl = v;
+#pragma unroll
+        for (int d = 1; d < WAVE; d <<= 1) {
+            const int o = __shfl_up(incl, d);
+            if (tid >= d) incl += o;
+        }
+        const int last = s_hist[64];
+        s_hist[tid] = incl - v;
+        if (tid == WAVE - 1) {
+            s_hist[64] = incl;                                                       // the cost-0 bucket comes after all others
+            s_hist[65] = incl + last;                                                // number of items
+            *count = incl + last;
+        }
     }
     __syncthreads();
     const int m = s_hist[65];
