@@ -481,3 +481,87 @@ def free_step(loc, vel, waypoint, target_speed, radius, crossing, draws, geom, p
         x_new = x_new.astype(np.float32).astype(np.float64)
         v_new = v_new.astype(np.float32).astype(np.float64)
     return x_new, v_new, wp, draws
+
+
+# --------------------------------------------------------------------------------------------------
+# independent float64 restatements used as checkers of the product's host twins and
+# device code.  PARITY UNPINNED: obstacles.py needs carla and check_traffic.py needs shapely, neither is installable here, and
+# the reference holds no fixtures for them -- these follow the source text and the documented semantics of the two libraries.
+# --------------------------------------------------------------------------------------------------
+def ellipse_ring(center, yaw, extent_x, extent_y, resolution=0.1, size_factor=np.sqrt(2.0)):
+    """generate_ellipse_border (obstacles.py:269-281): ``samples = max(6, int((2 ex + 2 ey) / resolution))`` points
+    (ex cos t, ey sin t) * size_factor for t = 2 pi i / samples, each moved by the vehicle transform -- with pitch = roll = 0,
+    carla.Transform.transform rotates by yaw about z and translates by the location.  yaw in radians.  Returns (samples, 2)."""
+    samples = max(6, int((2.0 * extent_x + 2.0 * extent_y) / resolution))
+    out = np.empty((samples, 2))
+    c, s = np.cos(yaw), np.sin(yaw)
+    for i in range(samples):
+        theta = np.pi * 2 * i / samples
+        px, py = extent_x * np.cos(theta) * size_factor, extent_y * np.sin(theta) * size_factor
+        out[i] = (center[0] + c * px - s * py, center[1] + s * px + c * py)
+    return out
+
+
+def _cross2(a, b):
+    return a[0] * b[1] - a[1] * b[0]
+
+
+def _segments_meet(p0, p1, q0, q1):
+    """What shapely's LineString([p0,p1]).intersection(LineString([q0,q1])) is, as a list of 0, 1 (point) or 2 (overlap
+    segment end points) points.  Written from the definitions: a point X is on both segments."""
+    d1, d2 = p1 - p0, q1 - q0
+    den = _cross2(d1, d2)
+    if den != 0.0:                                           # lines cross in exactly one point
+        t = _cross2(q0 - p0, d2) / den
+        u = _cross2(q0 - p0, d1) / den
+        return [p0 + t * d1] if (0.0 <= t <= 1.0 and 0.0 <= u <= 1.0) else []
+    if _cross2(q0 - p0, d1) != 0.0:                          # parallel, distinct lines
+        return []
+    L = float(d1 @ d1)
+    if L == 0.0:                                             # the pedestrian does not move: a point against a segment
+        M = float(d2 @ d2)
+        if M == 0.0:
+            return [p0] if (p0 == q0).all() else []
+        u = float((p0 - q0) @ d2) / M
+        return [p0] if 0.0 <= u <= 1.0 else []
+    a, b = sorted((float((q0 - p0) @ d1) / L, float((q1 - p0) @ d1) / L))   # q's extent along p's parameter
+    lo, hi = max(a, 0.0), min(b, 1.0)
+    if lo > hi:
+        return []
+    return [p0 + lo * d1] if lo == hi else [p0 + lo * d1, p0 + hi * d1]
+
+
+def _dist_to(points, x):
+    """shapely geometry.distance(Point(x)) for a point (1 entry) or a segment (2 entries)."""
+    if len(points) == 1:
+        return float(np.hypot(*(points[0] - x)))
+    a, b = points
+    ab = b - a
+    t = min(1.0, max(0.0, float((x - a) @ ab) / float(ab @ ab)))
+    return float(np.hypot(*(a + t * ab - x)))
+
+
+def gap_accepted(ped_loc, ped_goal, ped_speed, safety_margin, vehicle_locs, vehicle_velocities, vehicle_extents):
+    """check_traffic (check_traffic.py:7-61): may the pedestrian at ``ped_loc`` walk to ``ped_goal`` at ``ped_speed``?
+    Every vehicle's front / back is its position +- direction * vehicle_extents[:][0] -- the FIRST vehicle's (x, y) extent,
+    element-wise (:35-36, kept as written); its path runs from the back to front + v (time_ped + margin) (:42-43); if the paths
+    meet and the vehicle moves, the pedestrian waits when tti_front - margin < tti_ped < tti_back + margin (:52-58)."""
+    ped_loc, ped_goal = np.asarray(ped_loc, dtype=np.float64)[:2], np.asarray(ped_goal, dtype=np.float64)[:2]
+    if not safety_margin >= 0:                                                   # :24
+        return True
+    time_ped = np.linalg.norm(ped_goal - ped_loc) / ped_speed                    # :27-28
+    locs = np.asarray(vehicle_locs, dtype=np.float64).reshape(-1, 2)
+    vels = np.asarray(vehicle_velocities, dtype=np.float64).reshape(-1, 2)
+    dirs, _ = unit_and_norm(vels)                                                # :34
+    first_extent = np.asarray(vehicle_extents, dtype=np.float64).reshape(-1, 2)[0]
+    for loc, vel, d in zip(locs, vels, dirs):
+        front, back = loc + d * first_extent, loc - d * first_extent             # :35-36
+        meet = _segments_meet(ped_loc, ped_goal, back, front + vel * (time_ped + safety_margin))   # :42-46
+        if not meet:
+            continue
+        speed = np.linalg.norm(vel)
+        if speed != 0:                                                           # :49-50
+            tti_ped = _dist_to(meet, ped_loc) / ped_speed
+            if _dist_to(meet, front) / speed - safety_margin < tti_ped < _dist_to(meet, back) / speed + safety_margin:
+                return False
+    return True

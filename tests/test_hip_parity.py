@@ -441,8 +441,11 @@ def test_device_side_dynamic_obstacles_track_the_host_twin():
         draws = np.zeros(n, dtype=np.int64)
         for k in range(10):
             dev = eng.dynamic_obstacles()
-            for (c_d, r_d), (c_h, r_h) in zip(dev, sc.dynamic_obstacles):
+            for j, ((c_d, r_d), (c_h, r_h)) in enumerate(zip(dev, sc.dynamic_obstacles)):
                 assert np.array_equal(c_d, c_h) and np.array_equal(r_d, r_h), f"tick {k}"
+                # ... and the host twin itself against the oracle's float64 restatement of obstacles.py:269-281
+                want = O.ellipse_ring(c_h, sc.dynamic_yaw[j], *sc.dynamic_extent[j])
+                assert np.max(np.abs(r_d - want)) <= 4e-6 * max(1.0, np.abs(want).max()), f"tick {k}"
             geom = O.Geometry(dynamic_obstacles=sc.dynamic_obstacles, dynamic_vel=sc.dynamic_vel)
             with np.errstate(all="ignore"):
                 oloc, ovel, owp, draws = O.free_step(loc, vel, wp, sc.target_speed, sc.radius, np.zeros(n, bool), draws,

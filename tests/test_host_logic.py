@@ -188,3 +188,50 @@ def test_balanced_bounds_evens_out_a_lopsided_cost():
     assert first > 1.04 and spread < 1.005
     assert balanced_bounds([0, 128, 256], [0.0, 0.0], 256) == [0, 128, 256]     # no measure: boundaries stay
     assert balanced_bounds([0, 256], [5.0], 256) == [0, 256]
+
+
+def test_gap_acceptance_and_vehicle_rings_agree_with_the_oracles_restatement():
+    """SURVEY.md section 8f rows 2 and 3.  Neither obstacles.py (carla) nor check_traffic.py (shapely) can run here and the
+    reference holds no fixtures for them, so the product's host code is checked against an independent float64 restatement in
+    oracle/ written from the reference source (parity unpinned, stated in both places): 4000 random crossings incl. axis-aligned
+    and collinear ones, and the ellipse rings of random vehicles."""
+    from types import SimpleNamespace
+    from carla_social_force_model_amd import scenarios
+    from oracle import sfm_oracle as O
+    rng = np.random.default_rng(2024)
+    disagreements, waits = 0, 0
+    for k in range(4000):
+        m = int(rng.integers(1, 4))
+        snap = (lambda a: np.round(a)) if k % 3 == 0 else (lambda a: a)          # every third case on the integer grid: collinear / touching paths happen
+        loc, goal = snap(rng.uniform(-10, 10, 2)), snap(rng.uniform(-10, 10, 2))
+        if (loc == goal).all():
+            goal = goal + 1.0
+        vlocs, vvels = [], []
+        for _ in range(m):                                   # most vehicles are aimed at a point of the pedestrian's path
+            if rng.random() < 0.7:
+                tgt = loc + rng.uniform(0, 1) * (goal - loc)
+                h = rng.uniform(0, 2 * np.pi)
+                d = np.array([np.cos(h), np.sin(h)])
+                sp = rng.uniform(2, 12)
+                vlocs.append(snap(tgt - d * sp * rng.uniform(0, 8)))
+                vvels.append(snap(d * sp) * (rng.random() > 0.1))
+            else:
+                vlocs.append(snap(rng.uniform(-30, 30, 2)))
+                vvels.append(snap(rng.uniform(-12, 12, 2)) * (rng.random() > 0.1))
+        exts = [rng.uniform(0.5, 2.5, 2) for _ in range(m)]
+        speed, margin = float(rng.uniform(0.8, 2.0)), float(rng.choice([-1.0, 0.0, 0.5, 1.5]))
+        ped = {'loc': np.append(loc, 0.0), 'next_waypoint': np.append(goal, 0.0),
+               'mode': SimpleNamespace(crossing_speed=speed, crossing_safety_margin=margin)}
+        got = check_traffic(ped, [(v, None) for v in vlocs], vvels, exts)
+        want = O.gap_accepted(loc, goal, speed, margin, vlocs, vvels, exts)
+        disagreements += got != want
+        waits += not want
+    assert disagreements == 0 and 200 < waits < 3800
+    for _ in range(50):
+        c, yaw, ex, ey = rng.uniform(-500, 500, 2), rng.uniform(0, 2 * np.pi), rng.uniform(0.3, 3.0), rng.uniform(0.3, 1.5)
+        want = O.ellipse_ring(c, yaw, ex, ey)
+        local = scenarios.ring_local_offsets(ex, ey)
+        got = scenarios.place_ring_f32(c, yaw, local)
+        assert got.shape == want.shape
+        assert np.max(np.abs(got - want)) <= 1e-4                                  # fp32 placement at |c| ~ 500 m: ulp 6e-5
+        assert np.max(np.abs(scenarios.ellipse_ring(scenarios._f32(c), yaw, ex, ey) - want)) <= 1e-4
