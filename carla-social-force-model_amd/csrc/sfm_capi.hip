@@ -17,7 +17,7 @@
 namespace sfm {
 hipError_t launch_tick(int ipw, int team, bool z3, bool rad, const TickArgs& a, hipStream_t st);
 hipError_t launch_arrived(const float4* pk, const float4* own, int N, float thr2, uint8_t* mask, hipStream_t st);
-hipError_t launch_sym_list(const TickArgs& a, const SymArgs& sa, hipStream_t st, int partners = 0);
+hipError_t launch_sym_list(const TickArgs& a, const SymArgs& sa, hipStream_t st, int partners = 0, bool count_is_zero = false);
 hipError_t launch_sym_pair(bool rad, const TickArgs& a, const SymArgs& sa, hipStream_t st);
 hipError_t launch_sym_epilogue(bool rad, const TickArgs& a, const SymArgs& sa, hipStream_t st);
 hipError_t launch_schedule(const int* cost, int n_t, uint32_t* work, int* count, hipStream_t st);
@@ -106,6 +106,8 @@ struct SfmHandle {
     float* strip_vmax = nullptr;
     int box_cur = 0;
     bool boxes_valid = false;
+    bool count_zeroed = false;             // the last epilogue left the list counter at 0
+    int carry_mode = -1;                   // SFM_CARRY=0: boxes / list counter are rebuilt every tick (A/B)
     int geo_slices_override = 0;           // SFM_GEO_SLICES / SFM_STRIPS / SFM_DEBUG_STEPS, read once at sfm_create (tests, probes)
     int strips_override = -1;
     int debug_steps = -1;
@@ -286,6 +288,8 @@ int sfm_create(const SfmParams* params, int device_id, SfmHandle** out) {
     if (ov) h->sym_mode = atoi(ov);
     ov = getenv("SFM_CUTOFF");
     if (ov) h->cut_mode = atoi(ov);
+    ov = getenv("SFM_CARRY");
+    if (ov) h->carry_mode = atoi(ov);
     ov = getenv("SFM_SPLIT");
     if (ov) h->split_mode = atoi(ov);
     ov = getenv("SFM_GEO_AHEAD");
@@ -691,7 +695,7 @@ int sfm_upload_state(SfmHandle* h, int N, const float* x, const float* y, const 
     {
         const size_t items = (size_t)h->n_t * (size_t)(h->n_t / 2 + 1);
         if (h->n_t < 65536 && items > h->work_cap) { HIP_TRY(h, dev_realloc(h->work, items)); h->work_cap = items; }
-        if (!h->work_count) HIP_TRY(h, dev_realloc(h->work_count, (size_t)2));
+        if (!h->work_count) HIP_TRY(h, dev_realloc(h->work_count, (size_t)4));    // [0] list, [1] own-own list of a split tick, [2] copy of [0] left by a zeroing epilogue
         h->begin_done = false;
         if (h->n_t <= 128 && items > h->cost_cap) { HIP_TRY(h, dev_realloc(h->cost, items)); h->cost_cap = items; }
         h->sched_valid = false;
@@ -828,8 +832,12 @@ static void fill_args(SfmHandle* h, TickArgs& a, uint32_t flags) {
     const bool lite = lite_ok && !cut && h->cut_mode == 2;
     a.tile_box = (cut || lite) ? h->tile_box + (size_t)h->box_cur * h->n_t : nullptr;
     a.tile_vmax = (cut || lite) ? h->tile_vmax + (size_t)h->box_cur * h->n_t : nullptr;
-    a.tile_box_out = lite ? h->tile_box + (size_t)(h->box_cur ^ 1) * h->n_t : nullptr;
-    a.tile_vmax_out = lite ? h->tile_vmax + (size_t)(h->box_cur ^ 1) * h->n_t : nullptr;
+    // whole crowd on the symmetric path: the epilogue leaves the next tick's boxes (and, list cutoff, a zeroed list counter), so
+    // the next tick starts with its list kernel instead of a bounds kernel and a memset
+    const bool carry = lite || (cut && lite_ok && h->carry_mode != 0 && !h->fsm_on);
+    a.tile_box_out = carry ? h->tile_box + (size_t)(h->box_cur ^ 1) * h->n_t : nullptr;
+    a.tile_vmax_out = carry ? h->tile_vmax + (size_t)(h->box_cur ^ 1) * h->n_t : nullptr;
+    a.lite = lite ? 1 : 0;
     a.cut_scale = (float)((double)p.pedestrian.gamma * 41.0 * 0.6931471805599453 * 1.001);
     a.cut_pad = h->rad ? 2.0f * h->r_max * 1.001f : 0.f;
     if (h->fsm_on)
@@ -900,14 +908,15 @@ static void strip_shape(const SfmHandle* h, int* tps, int* n_strips) {
 
 // the symmetric path's view of one tick: slab, tile-pair list (list cutoff) or boxes (lite cutoff), strips, own tile range
 static SymArgs make_sym_args(const SfmHandle* h, const TickArgs& a, int tps, int n_strips, int debug_steps, unsigned long long* stamps) {
-    const bool lite = a.tile_box_out != nullptr;
+    const bool lite = a.lite != 0;
     const bool list = a.tile_box && !lite;
     const bool sched = lite && h->cost && h->sched_mode != 0 && (size_t)h->n_t * (size_t)(h->n_t / 2 + 1) <= h->cost_cap;
     return SymArgs{h->slab, h->tile_flag, h->n_t, slab_stride(h->n_t), h->dpp_dir, debug_steps,
                    (list || sched) ? h->work : nullptr, (list || sched) ? h->work_count : nullptr, lite ? a.tile_box : nullptr,
                    (lite || list) ? a.tile_vmax : nullptr,
                    a.cut_scale, a.cut_pad, stamps, h->strip_box, h->strip_vmax, tps, n_strips,
-                   h->i_begin / WAVE, (h->i_end + WAVE - 1) / WAVE, sched ? h->cost : nullptr, -1};
+                   h->i_begin / WAVE, (h->i_end + WAVE - 1) / WAVE, sched ? h->cost : nullptr, -1,
+                   (list && a.tile_box_out) ? 1 : 0};
 }
 
 constexpr int PHASE_FULL = 0, PHASE_BEGIN = 1, PHASE_END = 2;
@@ -934,7 +943,7 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags, int phase = PHASE_
         TickArgs probe;
         fill_args(h, probe, flags);
         order_pays = probe.geo != nullptr || probe.tile_box != nullptr;
-        list_cut = probe.tile_box != nullptr && probe.tile_box_out == nullptr;
+        list_cut = probe.tile_box != nullptr && !probe.lite;
     }
     // a shard can use it too when its rows are whole tiles and the tile-pair list is on: pairs with a tile of another
     // rank are then evaluated one-sided by both ranks
@@ -1004,8 +1013,9 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags, int phase = PHASE_
             HIP_TRY(h, launch_modes(a, h->stream));
             ++launches;
         }
-        const bool lite = a.tile_box_out != nullptr;
-        if (a.tile_box && !(lite && h->boxes_valid)) {   // boxes / speeds of this tick's input state (all tiles)
+        const bool lite = a.lite != 0;
+        const bool carried = a.tile_box_out != nullptr && h->boxes_valid;   // the previous epilogue left this tick's boxes
+        if (a.tile_box && !carried) {   // boxes / speeds of this tick's input state (all tiles)
             HIP_TRY(h, launch_tile_bounds(a.pk_cur, h->z3 ? a.zv_cur : nullptr, h->N, const_cast<float4*>(a.tile_box), const_cast<float*>(a.tile_vmax), h->stream));
             ++launches;
         }
@@ -1039,7 +1049,7 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags, int phase = PHASE_
                 ++launches;
             }
             if (sa.work && !sa.cost) {
-                HIP_TRY(h, launch_sym_list(a, sa, h->stream, finishing ? LIST_REMOTE : LIST_ALL));
+                HIP_TRY(h, launch_sym_list(a, sa, h->stream, finishing ? LIST_REMOTE : LIST_ALL, carried && h->count_zeroed));
                 ++launches;
             }
             HIP_TRY(h, launch_sym_pair(h->rad, a, sa, h->stream));
@@ -1064,8 +1074,14 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags, int phase = PHASE_
             ++launches;
         }
         // lite cutoff: the epilogue left the next tick's boxes in the other buffer (valid only if this tick moved the crowd)
-        if (lite && sym) { h->box_cur ^= 1; h->boxes_valid = (flags & SFM_TICK_INTEGRATE) != 0; }
-        else h->boxes_valid = false;
+        if (a.tile_box_out && sym) {
+            h->box_cur ^= 1;
+            h->boxes_valid = (flags & SFM_TICK_INTEGRATE) != 0;
+            h->count_zeroed = !lite;
+        } else {
+            h->boxes_valid = false;
+            h->count_zeroed = false;
+        }
         if (h->fsm_on) h->sim_time += h->prm.step_length;
         // CARLA-free runs: the vehicles move between ticks (run_simulation.py:77-95)
         if (a.adv.M > 0 && n_local <= 0) {          // a rank without rows still has to move its copy of the vehicles
@@ -1356,9 +1372,9 @@ int sfm_get_pair_work(SfmHandle* h, long long* tile_pair_items, long long* pair_
         return SFM_OK;
     }
     if (h->last_list) {
-        int cnt[2] = {0, 0};
-        HIP_TRY(h, hipMemcpy(cnt, h->work_count, sizeof(int) * 2, hipMemcpyDeviceToHost));
-        items = cnt[0] + (h->last_split ? cnt[1] : 0);          // split tick: the own-own items were listed separately
+        int cnt[3] = {0, 0, 0};
+        HIP_TRY(h, hipMemcpy(cnt, h->work_count, sizeof(int) * 3, hipMemcpyDeviceToHost));
+        items = (h->count_zeroed ? cnt[2] : cnt[0]) + (h->last_split ? cnt[1] : 0);   // split tick: the own-own items were listed separately
     } else {                                       // 2-D grid: every unordered tile pair once + the diagonal items
         const long long n_t = h->n_t;
         items = n_t * (n_t - 1) / 2 + diag_items;

@@ -102,8 +102,9 @@ struct TickArgs {
     const float* tile_vmax;   // [n_t] largest speed in the tile
     float cut_scale;          // gamma * 41 ln 2 (with margin): distance per unit of (lambda*(va+vb)+1)
     float cut_pad;            // 2 * largest radius when use_ped_radius, else 0
-    float4* tile_box_out;     // lite cutoff: the epilogue writes the boxes / speeds of the NEXT tick's state here
-    float* tile_vmax_out;
+    float4* tile_box_out;     // lite cutoff, and the list cutoff of a whole crowd: the symmetric epilogue writes the boxes / speeds of
+    float* tile_vmax_out;     // the NEXT tick's state here (saves the next tick's sfm_tile_bounds_kernel launch)
+    int lite;                 // 1: the "lite" cutoff (no tile-pair list) is what tile_box stands for
     FsmArgs fsm;
     unsigned long long* geo_stamps;   // diagnostic runs only (SFM_GEO_STAMPS): per geometry workgroup {start, after find, after scan, end} of s_memrealtime
 };
@@ -137,6 +138,7 @@ struct SymArgs {
     // cost[shift * n_t + bx] -- the next tick's order is dealt from those.  cost == null: off.
     int* cost;
     int sched_block;     // epilogue launch: index of the extra workgroup that deals the next tick's order (-1: none)
+    int zero_count;      // epilogue launch: 1 = leave *work_count at 0 for the next tick's list kernel (saves its memset)
 };
 
 }  // namespace sfm

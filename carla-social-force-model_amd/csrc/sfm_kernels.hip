@@ -1429,6 +1429,11 @@ __global__ __launch_bounds__(EPI_BLOCK) void sfm_sym_epilogue_kernel(const TickA
         if (k < a.adv.M) advance_vehicle(a.adv, k, lane, true);
         return;
     }
+    if (sa.zero_count && blockIdx.x == 0 && tid == 0) {     // this tick's pair kernel has read it: keep a copy for sfm_get_pair_work
+        int* wc = const_cast<int*>(sa.work_count);
+        wc[2] = wc[0];
+        wc[0] = 0;
+    }
     const int t = sa.t_lo + blockIdx.x;
     const int N = a.N;
     const int i_end = a.i_end;                             // rows of this handle end here (whole crowd: N)
@@ -1710,9 +1715,9 @@ hipError_t launch_geometry(bool rad, const TickArgs& a, hipStream_t st) {
 }
 
 // cutoff on: compact the tile pairs that have to be evaluated (the work list of the pair kernel)
-hipError_t launch_sym_list(const TickArgs& a, const SymArgs& sa, hipStream_t st, int partners = PARTNERS_ALL) {
+hipError_t launch_sym_list(const TickArgs& a, const SymArgs& sa, hipStream_t st, int partners = PARTNERS_ALL, bool count_is_zero = false) {
     if (a.N <= 1 || !a.en_ped || !sa.work || sa.cost) return hipSuccess;       // (scheduled mode: the order is dealt, not built)
-    hipError_t e = hipMemsetAsync(const_cast<int*>(sa.work_count), 0, sizeof(int), st);
+    hipError_t e = count_is_zero ? hipSuccess : hipMemsetAsync(const_cast<int*>(sa.work_count), 0, sizeof(int), st);
     if (e != hipSuccess) return e;
     const bool whole = sa.t_lo == 0 && sa.t_hi == sa.n_t;      // a shard also looks at partners behind it
     // own partners only (PARTNERS_OWN): the strips' boxes need every tile's box, which a shard does not have yet -- flat kernel
