@@ -1022,7 +1022,10 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags, int phase = PHASE_
         const bool ahead = (h->geo_ahead && a.geo && n_local > 0 && sym) ||   // launched at the end of the previous tick ...
                            (finishing && h->begin_forked);                     // ... or by sfm_tick_begin: join only
         h->geo_ahead = false;
-        const bool fork = a.geo && n_local > 0 && sym && (h->overlap_geo || finishing);
+        // (whole crowd with carried boxes: nothing small runs in front of the list / pair kernels any more, their resident grid
+        //  takes every wave slot before the side stream's workgroups get in and the two end up back to back behind a cross-stream
+        //  wait -- c3 65 us forked against 45 us in line; so the geometry kernel goes first, on the main stream)
+        const bool fork = a.geo && n_local > 0 && sym && ((h->overlap_geo && !(a.tile_box_out && !lite)) || finishing);
         if (ahead) {
         } else if (fork) {
             HIP_TRY(h, hipEventRecord(h->ev_fork, h->stream));
