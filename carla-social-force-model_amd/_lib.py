@@ -80,6 +80,7 @@ SYMBOLS = {
     "sfm_profile_dominant_kernel": (C.c_int, [_H, C.c_int, C.POINTER(C.c_float)]),
     "sfm_kernel_variant": (C.c_char_p, [_H]),
     "sfm_get_pair_work": (C.c_int, [_H, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
+    "sfm_set_partition": (C.c_int, [_H, C.c_int, C.c_int, _I]),
     "sfm_tick_begin": (C.c_int, [_H, C.c_uint32]),
     "sfm_tick_end": (C.c_int, [_H, C.c_uint32]),
 }
@@ -137,6 +138,8 @@ def u8ptr(a):
 
 
 def iptr(a):
+    if a is None:
+        return None
     assert a.dtype == np.int32 and a.flags["C_CONTIGUOUS"]
     return a.ctypes.data
 

@@ -29,6 +29,7 @@ hipError_t launch_modes(const TickArgs& a, hipStream_t st);
 struct ReorderBufs { unsigned long long *key64_in, *key64_out; uint32_t *row_a, *row_b, *key32_in, *key32_out; void* temp; size_t temp_bytes; };
 size_t reorder_temp_bytes(int N);
 hipError_t launch_resort(const float4* pk, int N, int strip_rows, const ReorderBufs& b, hipStream_t st);
+hipError_t launch_resort_blocks(const float4* pk, int N, const BlockPlan& pl, const ReorderBufs& b, hipStream_t st);
 hipError_t launch_unpack_rows(const char* block, size_t b_own, size_t b_zv, size_t b_rr, size_t b_cm, int n_pad, float4* pk0,
                               float4* pk1, float4* own, float2* zv0, float2* zv1, float* radius, uint8_t* crossing, uint32_t* draws,
                               hipStream_t st);
@@ -133,6 +134,10 @@ struct SfmHandle {
     size_t sort_temp_bytes = 0;
     int sort_cap = 0;
     int strip_rows = WAVE;                      // rows per x-strip of the spatial packing (multiple of 64)
+    // sharded runs (sfm_set_partition): gx x gy blocks, one per rank, each strip-packed on its own; part_gx = 0: off
+    double pack_aspect = 1.0;                   // x extent / y extent of the crowd at upload
+    int part_gx = 0, part_gy = 0;
+    std::vector<int> part_bounds;               // [gx*gy + 1] row bounds (empty: equal split of the padded row count)
     int resort_every = 64, ticks_since_sort = 0;
     bool perm_stale = false;
     float r_max = 0.f;
@@ -561,6 +566,31 @@ int sfm_download_dynamic_obstacles(SfmHandle* h, float* cx, float* cy, float* px
 // land on one HBM channel.
 static inline int slab_stride(int n_t) { return n_t * WAVE + WAVE; }
 
+// The packing plan of this handle: one block = plain strip packing, or the gx x gy blocks of sfm_set_partition with their row
+// bounds (equal split of the padded row count when none were given) and a strip size per block that makes its tiles square.
+static BlockPlan block_plan(const SfmHandle* h, int N, int n_pad) {
+    BlockPlan pl{};
+    const int G = h->part_gx * h->part_gy;
+    if (G <= 1 || G > MAX_BLOCKS) {
+        pl.n_blocks = 1; pl.gy = 1; pl.bound[0] = 0; pl.bound[1] = n_pad; pl.strip_rows[0] = h->strip_rows;
+        return pl;
+    }
+    pl.n_blocks = G;
+    pl.gy = h->part_gy;
+    for (int b = 0; b <= G; ++b)
+        pl.bound[b] = (int)h->part_bounds.size() == G + 1 ? h->part_bounds[b] : (int)((long long)n_pad * b / G / WAVE * WAVE);
+    pl.bound[0] = 0;
+    pl.bound[G] = std::max(pl.bound[G], n_pad);
+    // a block covers 1/gx of the extent in x and about 1/gy in y
+    const double aspect = std::fmin(std::fmax(h->pack_aspect * h->part_gy / h->part_gx, 1.0 / 64.0), 64.0);
+    for (int b = 0; b < G; ++b) {
+        const int tiles = std::max(1, (std::min(N, pl.bound[b + 1]) - std::min(N, pl.bound[b]) + WAVE - 1) / WAVE);
+        const int n_strips = std::max(1, std::min(tiles, (int)std::lround(std::sqrt((double)tiles * aspect))));
+        pl.strip_rows[b] = WAVE * ((tiles + n_strips - 1) / n_strips);
+    }
+    return pl;
+}
+
 int sfm_upload_state(SfmHandle* h, int N, const float* x, const float* y, const float* z, const float* vx,
                      const float* vy, const float* vz, const float* wx, const float* wy,
                      const float* target_speed, const float* radius, const uint8_t* crossing_mask) {
@@ -631,14 +661,29 @@ int sfm_upload_state(SfmHandle* h, int N, const float* x, const float* y, const 
         const int n_tiles = (N + WAVE - 1) / WAVE;
         double aspect = (x1 > x0 && y1 > y0) ? (double)(x1 - x0) / (double)(y1 - y0) : 1.0;
         aspect = std::fmin(std::fmax(aspect, 1.0 / 64.0), 64.0);
+        h->pack_aspect = aspect;
         const int n_strips = std::max(1, std::min(n_tiles, (int)std::lround(std::sqrt((double)n_tiles * aspect))));
         h->strip_rows = WAVE * ((n_tiles + n_strips - 1) / n_strips);
         std::vector<uint32_t> kx((size_t)N), ky((size_t)N);
         for (int i = 0; i < N; ++i) { kx[i] = float_key(x[i]); ky[i] = float_key(y[i]); }
-        std::stable_sort(h->perm.begin(), h->perm.end(), [&](uint32_t a_, uint32_t b_) { return kx[a_] < kx[b_]; });
-        for (int r0 = 0; r0 < N; r0 += h->strip_rows)
-            std::stable_sort(h->perm.begin() + r0, h->perm.begin() + std::min(N, r0 + h->strip_rows),
-                             [&](uint32_t a_, uint32_t b_) { return ky[a_] < ky[b_]; });
+        auto by_x = [&](uint32_t a_, uint32_t b_) { return kx[a_] < kx[b_]; };
+        auto by_y = [&](uint32_t a_, uint32_t b_) { return ky[a_] < ky[b_]; };
+        auto strip_pack = [&](int r0, int r1, int strip_rows) {         // rows [r0, r1) of perm: sort by x, strips, each by y
+            std::stable_sort(h->perm.begin() + r0, h->perm.begin() + r1, by_x);
+            for (int q = r0; q < r1; q += strip_rows) std::stable_sort(h->perm.begin() + q, h->perm.begin() + std::min(r1, q + strip_rows), by_y);
+        };
+        const BlockPlan pl = block_plan(h, N, n_pad);
+        if (pl.n_blocks <= 1) {
+            strip_pack(0, N, h->strip_rows);
+        } else {                                                          // block-major (sfm_set_partition): the device re-pack's four sorts
+            std::stable_sort(h->perm.begin(), h->perm.end(), by_x);
+            const int gx = pl.n_blocks / pl.gy;
+            for (int c = 0; c < gx; ++c) {
+                const int c0 = std::min(N, pl.bound[c * pl.gy]), c1 = std::min(N, pl.bound[(c + 1) * pl.gy]);
+                std::stable_sort(h->perm.begin() + c0, h->perm.begin() + c1, by_y);
+            }
+            for (int b = 0; b < pl.n_blocks; ++b) strip_pack(std::min(N, pl.bound[b]), std::min(N, pl.bound[b + 1]), pl.strip_rows[b]);
+        }
     }
     for (int s_ = 0; s_ < N; ++s_) {
         const int i = (int)h->perm[s_];
@@ -771,6 +816,21 @@ int sfm_set_shard(SfmHandle* h, int i_begin, int i_end) {
     return SFM_OK;
 }
 
+int sfm_set_partition(SfmHandle* h, int gx, int gy, const int32_t* bounds) {
+    if (!h) return SFM_ERR_INVALID;
+    if (gx < 0 || gy < 0 || (gx == 0) != (gy == 0) || gx * gy > MAX_BLOCKS) return fail(h, SFM_ERR_INVALID, "partition must be gx x gy blocks, at most 16");
+    const int G = gx * gy;
+    if (bounds) {
+        if (bounds[0] != 0) return fail(h, SFM_ERR_INVALID, "bounds[0] must be 0");
+        for (int b = 0; b < G; ++b)
+            if (bounds[b + 1] < bounds[b] || bounds[b] % WAVE) return fail(h, SFM_ERR_INVALID, "bounds must be non-decreasing multiples of 64");
+    }
+    h->part_gx = gx;
+    h->part_gy = gy;
+    h->part_bounds.assign(bounds ? bounds : nullptr, bounds ? bounds + G + 1 : nullptr);
+    return SFM_OK;
+}
+
 int sfm_set_waypoint_stream(SfmHandle* h, uint32_t seed, float world_side, float arrive_threshold) {
     if (!h) return SFM_ERR_INVALID;
     h->seed = seed;
@@ -875,7 +935,9 @@ static int resort_rows(SfmHandle* h) {
     uint32_t* w = h->sort_buf;                     // 8 N_pad words: two 64-bit key arrays, two row arrays, two 32-bit key arrays
     ReorderBufs b{reinterpret_cast<unsigned long long*>(w), reinterpret_cast<unsigned long long*>(w + 2 * (size_t)np_),
                   w + 4 * (size_t)np_, w + 5 * (size_t)np_, w + 6 * (size_t)np_, w + 7 * (size_t)np_, h->sort_temp, h->sort_temp_bytes};
-    HIP_TRY(h, launch_resort(h->pk[h->cur], N, h->strip_rows, b, h->stream));
+    const BlockPlan pl = block_plan(h, N, np_);
+    if (pl.n_blocks > 1) HIP_TRY(h, launch_resort_blocks(h->pk[h->cur], N, pl, b, h->stream));
+    else HIP_TRY(h, launch_resort(h->pk[h->cur], N, h->strip_rows, b, h->stream));
     HIP_TRY(h, launch_gather(b.row_b, N, h->pk[h->cur], h->pk[h->cur ^ 1], h->z3 ? h->zv[h->cur] : nullptr, h->zv[h->cur ^ 1],
                              h->own, h->own2, h->radius, h->radius2, h->crossing, h->crossing2, h->draws, h->draws2, h->ids,
                              h->ids2, h->stream));

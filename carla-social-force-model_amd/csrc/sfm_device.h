@@ -141,4 +141,14 @@ struct SymArgs {
     int zero_count;      // epilogue launch: 1 = leave *work_count at 0 for the next tick's list kernel (saves its memset)
 };
 
+// Block-major packing for sharded runs (sfm_set_partition, sfm_reorder.hip): the row order is cut into gx columns by x, each
+// column into gy blocks by y -- block b = column * gy + position holds rows [bound[b], bound[b+1]) -- and every block is
+// strip-packed on its own, so a rank's contiguous row range is a compact rectangle of the map instead of a slab across it.
+constexpr int MAX_BLOCKS = 16;
+struct BlockPlan {
+    int n_blocks, gy;                 // n_blocks = gx * gy (1: plain strip packing of the whole crowd)
+    int bound[MAX_BLOCKS + 1];        // row bounds of the blocks, multiples of 64, bound[n_blocks] >= N
+    int strip_rows[MAX_BLOCKS];       // rows per strip inside each block
+};
+
 }  // namespace sfm

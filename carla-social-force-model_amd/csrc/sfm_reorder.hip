@@ -84,6 +84,39 @@ hipError_t launch_unpack_rows(const char* block, size_t b_own, size_t b_zv, size
     return hipGetLastError();
 }
 
+__device__ __forceinline__ int plan_block_of(const BlockPlan& pl, int r) {       // block holding rank r of the block order
+    int b = 0;
+    while (b + 1 < pl.n_blocks && r >= pl.bound[b + 1]) ++b;
+    return b;
+}
+
+// rank r of the x order -> key (column, y): the columns take their row counts from the block bounds
+__global__ void sfm_column_keys_kernel(const float4* __restrict__ pk, int N, const BlockPlan pl, const uint32_t* __restrict__ row,
+                                       unsigned long long* __restrict__ key) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= N) return;
+    const int col = plan_block_of(pl, r) / pl.gy;
+    key[r] = ((unsigned long long)(uint32_t)col << 32) | float_key(pk[row[r]].y);
+}
+
+// rank r of the (column, y) order -> key (block, x)
+__global__ void sfm_block_keys_kernel(const float4* __restrict__ pk, int N, const BlockPlan pl, const uint32_t* __restrict__ row,
+                                      unsigned long long* __restrict__ key) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= N) return;
+    key[r] = ((unsigned long long)(uint32_t)plan_block_of(pl, r) << 32) | float_key(pk[row[r]].x);
+}
+
+// rank r of the (block, x) order -> key (block, strip inside the block, y)
+__global__ void sfm_block_strip_keys_kernel(const float4* __restrict__ pk, int N, const BlockPlan pl, const uint32_t* __restrict__ row,
+                                            unsigned long long* __restrict__ key) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= N) return;
+    const int b = plan_block_of(pl, r);
+    const uint32_t strip = (uint32_t)((r - pl.bound[b]) / pl.strip_rows[b]);
+    key[r] = ((unsigned long long)(((uint32_t)b << 20) | strip) << 32) | float_key(pk[row[r]].y);
+}
+
 struct ReorderBufs {
     unsigned long long *key64_in, *key64_out;
     uint32_t *row_a, *row_b, *key32_in, *key32_out;   // the final order is in row_b: row_b[s] = old row that moves to row s
@@ -98,6 +131,30 @@ size_t reorder_temp_bytes(int N) {
     rocprim::radix_sort_pairs(nullptr, b32, p, p, p, p, (size_t)N, 0, 32, nullptr);
     rocprim::radix_sort_pairs(nullptr, b64, q, q, p, p, (size_t)N, 0, 64, nullptr);
     return b32 > b64 ? b32 : b64;
+}
+
+// x sort, then (column, y), (block, x), (block, strip, y): four radix sorts; the final order is in row_b
+hipError_t launch_resort_blocks(const float4* pk, int N, const BlockPlan& pl, const ReorderBufs& b, hipStream_t st) {
+    const dim3 grid((N + 255) / 256), block(256);
+    hipLaunchKernelGGL(sfm_x_keys_kernel, grid, block, 0, st, pk, N, b.key32_in, b.row_b);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    size_t bytes = b.temp_bytes;
+    e = rocprim::radix_sort_pairs(b.temp, bytes, b.key32_in, b.key32_out, b.row_b, b.row_a, (size_t)N, 0, 32, st);      // -> row_a
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(sfm_column_keys_kernel, grid, block, 0, st, pk, N, pl, b.row_a, b.key64_in);
+    bytes = b.temp_bytes;
+    e = rocprim::radix_sort_pairs(b.temp, bytes, b.key64_in, b.key64_out, b.row_a, b.row_b, (size_t)N, 0, 40, st);        // -> row_b
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(sfm_block_keys_kernel, grid, block, 0, st, pk, N, pl, b.row_b, b.key64_in);
+    bytes = b.temp_bytes;
+    e = rocprim::radix_sort_pairs(b.temp, bytes, b.key64_in, b.key64_out, b.row_b, b.row_a, (size_t)N, 0, 40, st);        // -> row_a
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(sfm_block_strip_keys_kernel, grid, block, 0, st, pk, N, pl, b.row_a, b.key64_in);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    bytes = b.temp_bytes;
+    return rocprim::radix_sort_pairs(b.temp, bytes, b.key64_in, b.key64_out, b.row_a, b.row_b, (size_t)N, 0, 64, st);     // -> row_b
 }
 
 hipError_t launch_resort(const float4* pk, int N, int strip_rows, const ReorderBufs& b, hipStream_t st) {

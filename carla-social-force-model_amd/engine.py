@@ -208,6 +208,11 @@ class SfmEngine:
         self._check(self._lib.sfm_set_shard(self._h, int(i_begin), int(i_end)), "sfm_set_shard")
         self.shard = (int(i_begin), int(i_end))
 
+    def set_partition(self, gx, gy, bounds=None):
+        """Block-major row packing for sharded runs (sfm_set_partition): gx x gy blocks, block b = rows [bounds[b], bounds[b+1])."""
+        b = None if bounds is None else np.ascontiguousarray(bounds, dtype=np.int32)
+        self._check(self._lib.sfm_set_partition(self._h, int(gx), int(gy), iptr(b)), "sfm_set_partition")
+
     def set_waypoint_stream(self, seed, world_side, arrive_threshold=2.0):
         self._check(self._lib.sfm_set_waypoint_stream(self._h, int(seed) & 0xFFFFFFFF, float(world_side),
                                                       float(arrive_threshold)), "sfm_set_waypoint_stream")

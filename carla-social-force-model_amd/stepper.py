@@ -34,6 +34,21 @@ ROW_COST_TERMS = 600             # HipShardEngine.work(): per-row cost of a tick
 GEOMETRY_ROW_COST_TERMS = 1000   # ... and of the border / obstacle forces
 
 
+def block_layout(world):
+    """(gx, gy) of the rank blocks, gx columns by x times gy blocks by y: as square as the rank count allows
+    (2 -> 1x2, 4 -> 2x2, 8 -> 2x4).  SFM_LAYOUT=gx,gy overrides (e.g. "8,1" = the slabs of round 1)."""
+    ov = os.environ.get("SFM_LAYOUT")
+    if ov:
+        gx, gy = (int(v) for v in ov.split(","))
+        if gx * gy != world:
+            raise ValueError(f"SFM_LAYOUT={ov} does not make {world} blocks")
+        return gx, gy
+    gy = 1
+    while gy * gy * 2 <= world and world % (gy * 2) == 0:
+        gy *= 2
+    return world // gy, gy
+
+
 def equal_bounds(n, n_pad, world):
     """[b_0 = 0, b_1, ..., b_world = n]: the equal split as a bounds list."""
     return [shard_bounds(n, n_pad, r, world)[0] for r in range(world)] + [n]
@@ -114,6 +129,9 @@ class HipShardEngine:
     def set_shard(self, lo, hi):
         self.engine.set_shard(lo, hi)
 
+    def set_partition(self, gx, gy, bounds=None):
+        self.engine.set_partition(gx, gy, bounds)
+
     def run(self, ticks, redraw=True):
         self.engine.run(ticks, redraw=redraw)
 
@@ -188,10 +206,16 @@ class ShardedStepper:
 
     def __init__(self, engine, scenario, rank=0, world=1, group=None, redraw=True, resort_every=None, balance=None):
         self.engine, self.rank, self.world, self.group, self.redraw = engine, rank, world, group, redraw
+        # rank blocks instead of slabs: every rank's rows are the pedestrians of one rectangle of a gx x gy grid over the map
+        self.layout = block_layout(world) if (world > 1 and hasattr(engine, "set_partition")) else None
+        if self.layout:
+            engine.set_partition(*self.layout)
         self.n, self.n_pad = engine.load(scenario, redraw=redraw)
         self.bounds = equal_bounds(self.n, self.n_pad, world)
         self.lo, self.hi = self.bounds[rank], self.bounds[rank + 1]
         engine.set_shard(self.lo, self.hi)
+        if self.layout:
+            engine.set_partition(*self.layout, self.bounds)
         self.ticks_done = 0
         # rows are kept spatially packed (compact 64-row tiles); pedestrians walk, so the packing is renewed every
         # `resort_every` ticks.  One rank: the engine does it itself.  Shards: gather the owner-only per-row arrays,
@@ -295,6 +319,8 @@ class ShardedStepper:
         self.bounds = list(bounds)
         self.lo, self.hi = self.bounds[self.rank], self.bounds[self.rank + 1]
         self.engine.set_shard(self.lo, self.hi)
+        if self.layout:
+            self.engine.set_partition(*self.layout, self.bounds)      # the next re-pack cuts the blocks at the new boundaries
 
     def step(self, ticks=1):
         """``ticks`` ticks.  Sharded: the exchange of tick t's rows is started right after tick t and only waited for

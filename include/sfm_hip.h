@@ -125,6 +125,12 @@ int sfm_upload_state(SfmHandle* h, int N,
  * bounds are multiples of 64 can use the symmetric pair kernel.  Every download writes a row's result at the CALLER's
  * index of that pedestrian; entries of pedestrians outside the shard are left untouched. */
 int sfm_set_shard(SfmHandle* h, int i_begin, int i_end);
+/* Row packing for sharded runs (no reference counterpart): cut the spatial packing into gx columns by x
+ * and each column into gy blocks by y, block b = column * gy + position holding rows [bounds[b], bounds[b+1]) (multiples of
+ * 64; NULL = equal split), every block strip-packed on its own.  A rank that owns the rows of one block then holds a compact
+ * rectangle of the map instead of a slab across it: less boundary, fewer tile pairs evaluated one-sided by two ranks.  Takes
+ * effect at the next sfm_upload_state / sfm_resort; gx = gy = 0 switches it off.  Results never depend on the packing. */
+int sfm_set_partition(SfmHandle* h, int gx, int gy, const int32_t* bounds);
 
 /* Counter-based waypoint stream of the synthetic scenarios: on arrival within `arrive_threshold`
  * (run_simulation.py:39) pedestrian i draws waypoint number k from hash(seed, i, k) in [0, world_side)^2. */
