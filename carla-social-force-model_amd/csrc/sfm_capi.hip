@@ -24,6 +24,8 @@ hipError_t launch_schedule(const int* cost, int n_t, uint32_t* work, int* count,
 int sym_item_count(int n_t);
 hipError_t launch_strip_bounds(const float4* box, const float* vmax, int n_t, int tps, int n_strips, float4* sbox, float* svmax,
                                hipStream_t st);
+hipError_t launch_tile_strip_bounds(const float4* pk, int N, int n_t, int tps, int n_strips, float4* box, float* vmax, float4* sbox,
+                                    float* svmax, hipStream_t st);
 hipError_t launch_geometry(bool rad, const TickArgs& a, hipStream_t st);
 hipError_t launch_modes(const TickArgs& a, hipStream_t st);
 struct ReorderBufs { unsigned long long *key64_in, *key64_out; uint32_t *row_a, *row_b, *key32_in, *key32_out; void* temp; size_t temp_bytes; };
@@ -978,7 +980,7 @@ static SymArgs make_sym_args(const SfmHandle* h, const TickArgs& a, int tps, int
                    (lite || list) ? a.tile_vmax : nullptr,
                    a.cut_scale, a.cut_pad, stamps, h->strip_box, h->strip_vmax, tps, n_strips,
                    h->i_begin / WAVE, (h->i_end + WAVE - 1) / WAVE, sched ? h->cost : nullptr, -1,
-                   (list && a.tile_box_out) ? 1 : 0};
+                   (list && a.tile_box_out) ? 1 : 0};      // (shards: run_ticks sets it, it knows whether the tick integrates)
 }
 
 constexpr int PHASE_FULL = 0, PHASE_BEGIN = 1, PHASE_END = 2;
@@ -1045,7 +1047,7 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags, int phase = PHASE_
         SymArgs sa = make_sym_args(h, a, tps, 0, h->debug_steps, nullptr);
         sa.work = h->work2;
         sa.work_count = h->work_count + 1;
-        HIP_TRY(h, launch_sym_list(a, sa, h->stream, LIST_OWN));
+        HIP_TRY(h, launch_sym_list(a, sa, h->stream, LIST_OWN, h->count_zeroed));
         HIP_TRY(h, launch_sym_pair(h->rad, a, sa, h->stream));
         h->begin_done = true;
         h->begin_flags = flags;
@@ -1066,6 +1068,7 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags, int phase = PHASE_
             launches += 5;
         }
         if (!finishing) ++h->ticks_since_sort;
+        bool shard_zeroed = false;
         TickArgs a;
         fill_args(h, a, flags);
         // border / obstacle forces only need the tick's input state.  With the symmetric path they run on the side
@@ -1077,7 +1080,13 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags, int phase = PHASE_
         }
         const bool lite = a.lite != 0;
         const bool carried = a.tile_box_out != nullptr && h->boxes_valid;   // the previous epilogue left this tick's boxes
-        if (a.tile_box && !carried) {   // boxes / speeds of this tick's input state (all tiles)
+        // boxes / speeds of this tick's input state (all tiles); with the two-level list the strips' boxes come out of the same launch
+        const bool merged_bounds = a.tile_box && !carried && sym && list_cut && n_strips > 0 && !h->z3;
+        if (merged_bounds) {
+            HIP_TRY(h, launch_tile_strip_bounds(a.pk_cur, h->N, h->n_t, tps, n_strips, const_cast<float4*>(a.tile_box),
+                                                const_cast<float*>(a.tile_vmax), h->strip_box, h->strip_vmax, h->stream));
+            ++launches;
+        } else if (a.tile_box && !carried) {
             HIP_TRY(h, launch_tile_bounds(a.pk_cur, h->z3 ? a.zv_cur : nullptr, h->N, const_cast<float4*>(a.tile_box), const_cast<float*>(a.tile_vmax), h->stream));
             ++launches;
         }
@@ -1109,17 +1118,23 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags, int phase = PHASE_
                 h->sched_valid = true;
                 ++launches;
             }
-            if (sa.work && !sa.cost && n_strips > 0) {
+            if (sa.work && !sa.cost && n_strips > 0 && !merged_bounds) {
                 HIP_TRY(h, launch_strip_bounds(a.tile_box, a.tile_vmax, h->n_t, tps, n_strips, h->strip_box, h->strip_vmax, h->stream));
                 ++launches;
             }
+            // a shard's epilogue leaves the list counter(s) at zero as well (its boxes cannot be carried -- the other ranks' rows
+            // arrive in between -- but the memset can go)
+            const bool shard_zero = !whole && list_cut && !sa.cost && (flags & SFM_TICK_INTEGRATE) && h->carry_mode != 0;
             if (sa.work && !sa.cost) {
-                HIP_TRY(h, launch_sym_list(a, sa, h->stream, finishing ? LIST_REMOTE : LIST_ALL, carried && h->count_zeroed));
+                HIP_TRY(h, launch_sym_list(a, sa, h->stream, finishing ? LIST_REMOTE : LIST_ALL, (carried || !whole) && h->count_zeroed));
                 ++launches;
             }
             HIP_TRY(h, launch_sym_pair(h->rad, a, sa, h->stream));
             if (fork) HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
-            HIP_TRY(h, launch_sym_epilogue(h->rad, a, sa, h->stream));
+            SymArgs se = sa;
+            if (shard_zero) se.zero_count = 2;
+            HIP_TRY(h, launch_sym_epilogue(h->rad, a, se, h->stream));
+            shard_zeroed = shard_zero;
             launches += 2;
         } else if (n_local > 0) {
             HIP_TRY(h, launch_tick(ipw, team, h->z3, h->rad, a, h->stream));
@@ -1145,7 +1160,7 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags, int phase = PHASE_
             h->count_zeroed = !lite;
         } else {
             h->boxes_valid = false;
-            h->count_zeroed = false;
+            h->count_zeroed = shard_zeroed;
         }
         if (h->fsm_on) h->sim_time += h->prm.step_length;
         // CARLA-free runs: the vehicles move between ticks (run_simulation.py:77-95)
@@ -1437,9 +1452,10 @@ int sfm_get_pair_work(SfmHandle* h, long long* tile_pair_items, long long* pair_
         return SFM_OK;
     }
     if (h->last_list) {
-        int cnt[3] = {0, 0, 0};
-        HIP_TRY(h, hipMemcpy(cnt, h->work_count, sizeof(int) * 3, hipMemcpyDeviceToHost));
-        items = (h->count_zeroed ? cnt[2] : cnt[0]) + (h->last_split ? cnt[1] : 0);   // split tick: the own-own items were listed separately
+        int cnt[4] = {0, 0, 0, 0};
+        HIP_TRY(h, hipMemcpy(cnt, h->work_count, sizeof(int) * 4, hipMemcpyDeviceToHost));
+        // (a zeroing epilogue kept copies in [2], [3]; split tick: the own-own items were listed separately, in [1])
+        items = (h->count_zeroed ? cnt[2] : cnt[0]) + (h->last_split ? (h->count_zeroed ? cnt[3] : cnt[1]) : 0);
     } else {                                       // 2-D grid: every unordered tile pair once + the diagonal items
         const long long n_t = h->n_t;
         items = n_t * (n_t - 1) / 2 + diag_items;

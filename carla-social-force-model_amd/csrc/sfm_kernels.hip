@@ -1054,6 +1054,50 @@ __global__ __launch_bounds__(WAVE) void sfm_strip_bounds_kernel(const float4* __
     if (lane == 0) { sbox[s] = make_float4(x0, y0, x1, y1); svmax[s] = v; }
 }
 
+// Both in one launch (large crowds with the two-level list): one 16-wave workgroup per strip, wave w takes tiles w, w+16, ... of
+// the strip, leaves each tile's box / largest speed and the workgroup combines the strip's.
+constexpr int TSB_WAVES = 16;
+__global__ __launch_bounds__(TSB_WAVES * WAVE) void sfm_tile_strip_bounds_kernel(const float4* __restrict__ pk, int N, int n_t, int tps,
+                                                                                 float4* __restrict__ box, float* __restrict__ vmax,
+                                                                                 float4* __restrict__ sbox, float* __restrict__ svmax) {
+    __shared__ float s_part[TSB_WAVES][5];
+    const int s = blockIdx.x, lane = threadIdx.x & (WAVE - 1);
+    const int wave = uniform((int)(threadIdx.x >> 6));
+    const float inf = __builtin_inff();
+    float sx0 = inf, sy0 = inf, sx1 = -inf, sy1 = -inf, sv = 0.0f;            // this wave's share of the strip (uniform)
+    for (int q = wave; q < tps; q += TSB_WAVES) {
+        const int t = s * tps + q;
+        if (t >= n_t) break;
+        const int i = t * WAVE + lane;
+        float x0 = inf, y0 = inf, x1 = -inf, y1 = -inf, v = 0.0f;
+        if (i < N) {
+            const float4 p = pk[i];
+            if (fabsf(p.x) < 1.0e14f) {
+                x0 = x1 = p.x; y0 = y1 = p.y;
+                v = sqrtf(fmaf(p.z, p.z, p.w * p.w)) * 1.000001f;
+            }
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            x0 = fminf(x0, __shfl_xor(x0, m)); y0 = fminf(y0, __shfl_xor(y0, m));
+            x1 = fmaxf(x1, __shfl_xor(x1, m)); y1 = fmaxf(y1, __shfl_xor(y1, m));
+            v = fmaxf(v, __shfl_xor(v, m));
+        }
+        if (lane == 0) { box[t] = make_float4(x0, y0, x1, y1); vmax[t] = v; }
+        sx0 = fminf(sx0, x0); sy0 = fminf(sy0, y0); sx1 = fmaxf(sx1, x1); sy1 = fmaxf(sy1, y1); sv = fmaxf(sv, v);
+    }
+    if (lane == 0) { s_part[wave][0] = sx0; s_part[wave][1] = sy0; s_part[wave][2] = sx1; s_part[wave][3] = sy1; s_part[wave][4] = sv; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < TSB_WAVES; ++w) {
+            sx0 = fminf(sx0, s_part[w][0]); sy0 = fminf(sy0, s_part[w][1]); sx1 = fmaxf(sx1, s_part[w][2]); sy1 = fmaxf(sy1, s_part[w][3]);
+            sv = fmaxf(sv, s_part[w][4]);
+        }
+        sbox[s] = make_float4(sx0, sy0, sx1, sy1);
+        svmax[s] = sv;
+    }
+}
+
 // Compacts the tile-pair items the symmetric kernel has to evaluate: one candidate per thread, (bx, shift) with
 // bx an own tile and tb = bx + shift (mod n_t).  Own-own pairs are kept once (shift <= n_t / 2, as in the kernel's 2-D
 // grid); a pair with a tile of another rank is kept by both ranks, each evaluating its own side only (bit 31).
@@ -1094,8 +1138,12 @@ __global__ __launch_bounds__(BLOCK) void sfm_pair_list2_kernel(const float4* __r
     __shared__ uint32_t s_item[WAVES_PER_BLOCK][BUF];
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = uniform((int)(threadIdx.x >> 6));
+    // one wave per own tile.  The list's single counter is what this kernel waits for (one device-scope atomic costs ~11 ns on one
+    // word: 4096 of them were 46 of the kernel's 54 us at c5), so a wave only appends on its own when its LDS buffer overflows;
+    // at the end the 4 waves of a workgroup reserve their space with ONE atomic.
+    __shared__ int s_n[WAVES_PER_BLOCK], s_base;
     const int bx = sa.t_lo + blockIdx.x * WAVES_PER_BLOCK + wave;
-    if (bx >= sa.t_hi) return;
+    const bool live = bx < sa.t_hi;
     uint32_t* buf = s_item[wave];
     int n_buf = 0;                                         // uniform
     auto flush = [&]() {
@@ -1107,9 +1155,9 @@ __global__ __launch_bounds__(BLOCK) void sfm_pair_list2_kernel(const float4* __r
         n_buf = 0;
     };
     const int n_t = sa.n_t;
-    const float4 bt = box[bx];
-    const float vt = vmax[bx];
-    for (int sb = 0; sb < sa.n_strips; sb += WAVE) {
+    const float4 bt = box[live ? bx : sa.t_lo];
+    const float vt = vmax[live ? bx : sa.t_lo];
+    for (int sb = 0; live && sb < sa.n_strips; sb += WAVE) {
         const int s = sb + lane;
         const bool hit = s < sa.n_strips && !tiles_negligible(bt, vt, sa.sbox[min(s, sa.n_strips - 1)], sa.svmax[min(s, sa.n_strips - 1)],
                                                               lam, sa.cut_scale, sa.cut_pad);
@@ -1163,7 +1211,16 @@ __global__ __launch_bounds__(BLOCK) void sfm_pair_list2_kernel(const float4* __r
             s0 = ns0; q0 = nq0; cb = nb; cv = nv; c_ok = n_ok;
         }
     }
-    flush();
+    if (lane == 0) s_n[wave] = n_buf;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int total = (s_n[0] + s_n[1]) + (s_n[2] + s_n[3]);
+        s_base = total ? atomicAdd(count, total) : 0;
+    }
+    __syncthreads();
+    int base = s_base;
+    for (int w = 0; w < wave; ++w) base += s_n[w];
+    for (int q = lane; q < n_buf; q += WAVE) work[base + q] = buf[q];
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1429,10 +1486,11 @@ __global__ __launch_bounds__(EPI_BLOCK) void sfm_sym_epilogue_kernel(const TickA
         if (k < a.adv.M) advance_vehicle(a.adv, k, lane, true);
         return;
     }
-    if (sa.zero_count && blockIdx.x == 0 && tid == 0) {     // this tick's pair kernel has read it: keep a copy for sfm_get_pair_work
+    if (sa.zero_count && blockIdx.x == 0 && tid == 0) {     // this tick's pair kernels have read them: keep copies for sfm_get_pair_work
         int* wc = const_cast<int*>(sa.work_count);
         wc[2] = wc[0];
         wc[0] = 0;
+        if (sa.zero_count > 1) { wc[3] = wc[1]; wc[1] = 0; }   // split tick: the own-own list's counter too
     }
     const int t = sa.t_lo + blockIdx.x;
     const int N = a.N;
@@ -1762,6 +1820,13 @@ hipError_t launch_tile_bounds(const float4* pk, const float2* zv, int N, float4*
     if (t_hi < 0) t_hi = (N + WAVE - 1) / WAVE;                 // default: every tile
     if (t_hi <= t_lo) return hipSuccess;
     hipLaunchKernelGGL(sfm_tile_bounds_kernel, dim3(t_hi - t_lo), dim3(WAVE), 0, st, pk, zv, N, box, vmax, t_lo);
+    return hipGetLastError();
+}
+
+hipError_t launch_tile_strip_bounds(const float4* pk, int N, int n_t, int tps, int n_strips, float4* box, float* vmax, float4* sbox,
+                                    float* svmax, hipStream_t st) {
+    if (N <= 0 || n_strips <= 0) return hipSuccess;
+    hipLaunchKernelGGL(sfm_tile_strip_bounds_kernel, dim3(n_strips), dim3(TSB_WAVES * WAVE), 0, st, pk, N, n_t, tps, box, vmax, sbox, svmax);
     return hipGetLastError();
 }
 
