@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG_DIR, "libsfm_hip.so")
+LIB_PATH = os.environ.get("SFM_LIB_PATH") or os.path.join(PKG_DIR, "libsfm_hip.so")   # (the override is for A/B builds of the kernels)
 ABI_VERSION = 1
 
 FORCE_NAMES = ("acceleration_force", "pedestrian_force", "border_force",

@@ -1342,12 +1342,15 @@ __global__ __launch_bounds__(BLOCK) void sfm_pair_sym_kernel(const float4* __res
         };
         // sigma = 32 on a diagonal tile meets every unordered pair {l, l+32} in BOTH lanes: one-sided there
         const bool tail_one_sided = diag && (sig0 + nsteps - 1 == 32);        // uniform
-        if (nsteps == 16) {                      // the normal case: fixed trip count, steps interleaved 3-way
+        // (not unrolled: measured on MI355X, round 2 -- c2 pair kernel 14.96 us at unroll 1, 16.7 / 15.6 / 16.7 / 15.9 at 2 / 3 / 4 / 5;
+        //  c5 854 against 896 us per tick at 3.  Eight waves per SIMD already hide a step's dependent chain; interleaving steps in
+        //  one wave only costs registers and a longer schedule.)
+        if (nsteps == 16) {                      // the normal case: fixed trip count
             if (one_sided) {
-#pragma unroll 4
+#pragma unroll 1
                 for (int s = 0; s < 16; ++s) step(false);
             } else {
-#pragma unroll 3
+#pragma unroll 1
                 for (int s = 0; s < 15; ++s) step(true);
                 if (tail_one_sided) step(false); else step(true);
             }
