@@ -1469,23 +1469,22 @@ __global__ __launch_bounds__(1024) void sfm_schedule_kernel(const int* __restric
 // order) and wave 0 integrates the 64 pedestrians lane-parallel with coalesced loads and stores (geometry
 // forces come from sfm_geometry_kernel).  Latency-bound by design: few, short chains.
 constexpr int EPI_WAVES = 16;
-constexpr int EPI_BLOCK = EPI_WAVES * WAVE;
 
-template <bool RAD>
-__global__ __launch_bounds__(EPI_BLOCK) void sfm_sym_epilogue_kernel(const TickArgs a, const SymArgs sa) {
-    __shared__ float2 s_sum[EPI_WAVES][WAVE];
+template <bool RAD, int EW>
+__global__ __launch_bounds__(EW * WAVE) void sfm_sym_epilogue_kernel(const TickArgs a, const SymArgs sa) {
+    __shared__ float2 s_sum[EW][WAVE];
     __shared__ float2 s_exact[WAVE];
-    __shared__ int s_bad[EPI_WAVES];
+    __shared__ int s_bad[EW];
     const int tid = threadIdx.x;
     const int lane = tid & (WAVE - 1);
     const int wave = uniform(tid >> 6);
     if (sa.sched_block >= 0 && (int)blockIdx.x == sa.sched_block) {  // one more extra workgroup: the next tick's item order
         __shared__ int s_hist[66];
-        sfm_schedule_items(sa.cost, sa.n_t, const_cast<uint32_t*>(sa.work), const_cast<int*>(sa.work_count), tid, EPI_BLOCK, s_hist);
+        sfm_schedule_items(sa.cost, sa.n_t, const_cast<uint32_t*>(sa.work), const_cast<int*>(sa.work_count), tid, (EW * WAVE), s_hist);
         return;
     }
     if (a.adv.M > 0 && (int)blockIdx.x >= a.adv.block0) {            // the extra workgroups: vehicles move on
-        const int k = ((int)blockIdx.x - a.adv.block0) * EPI_WAVES + wave;
+        const int k = ((int)blockIdx.x - a.adv.block0) * EW + wave;
         if (k < a.adv.M) advance_vehicle(a.adv, k, lane, true);
         return;
     }
@@ -1514,7 +1513,7 @@ __global__ __launch_bounds__(EPI_BLOCK) void sfm_sym_epilogue_kernel(const TickA
         const float2* col = sa.slab + i;
         const float4 bt = a.tile_box[t];
         const float vt = a.tile_vmax[t];
-        for (int s = wave; s < sa.n_strips; s += EPI_WAVES) {
+        for (int s = wave; s < sa.n_strips; s += EW) {
             if (tiles_negligible(bt, vt, sa.sbox[s], sa.svmax[s], a.ped.lam, a.cut_scale, a.cut_pad)) continue;   // uniform
             for (int q0 = 0; q0 < sa.tps; q0 += WAVE) {
                 const int u0 = s * sa.tps + q0, u = u0 + lane;
@@ -1544,8 +1543,8 @@ __global__ __launch_bounds__(EPI_BLOCK) void sfm_sym_epilogue_kernel(const TickA
         const float2* col = sa.slab + i;
         const float4 bt = a.tile_box[t];
         const float vt = a.tile_vmax[t];
-        for (int base = wave; base < sa.n_t; base += EPI_WAVES * WAVE) {
-            const int u = base + EPI_WAVES * lane;
+        for (int base = wave; base < sa.n_t; base += EW * WAVE) {
+            const int u = base + EW * lane;
             bool keep = false;
             if (u < sa.n_t) keep = !tiles_negligible(bt, vt, a.tile_box[u], a.tile_vmax[u], a.ped.lam, a.cut_scale, a.cut_pad);
             unsigned long long m = __ballot(keep);
@@ -1557,7 +1556,7 @@ __global__ __launch_bounds__(EPI_BLOCK) void sfm_sym_epilogue_kernel(const TickA
                     if (m) {
                         const int b = __ffsll((long long)m) - 1;
                         m &= m - 1;
-                        v[q] = col[(size_t)(base + EPI_WAVES * b) * sa.stride];
+                        v[q] = col[(size_t)(base + EW * b) * sa.stride];
                     }
                 }
                 acc.x += (v[0].x + v[1].x) + (v[2].x + v[3].x);
@@ -1567,13 +1566,13 @@ __global__ __launch_bounds__(EPI_BLOCK) void sfm_sym_epilogue_kernel(const TickA
     } else if (a.en_ped) {                                   // wave w takes partner tiles w, w+16, ...
         const float2* col = sa.slab + i;
         int u = wave;
-        for (; u + 3 * EPI_WAVES < sa.n_t; u += 4 * EPI_WAVES) {          // 4 independent loads in flight
-            const float2 v0 = col[(size_t)u * sa.stride], v1 = col[(size_t)(u + EPI_WAVES) * sa.stride];
-            const float2 v2 = col[(size_t)(u + 2 * EPI_WAVES) * sa.stride], v3 = col[(size_t)(u + 3 * EPI_WAVES) * sa.stride];
+        for (; u + 3 * EW < sa.n_t; u += 4 * EW) {          // 4 independent loads in flight
+            const float2 v0 = col[(size_t)u * sa.stride], v1 = col[(size_t)(u + EW) * sa.stride];
+            const float2 v2 = col[(size_t)(u + 2 * EW) * sa.stride], v3 = col[(size_t)(u + 3 * EW) * sa.stride];
             acc.x += (v0.x + v1.x) + (v2.x + v3.x);
             acc.y += (v0.y + v1.y) + (v2.y + v3.y);
         }
-        for (; u < sa.n_t; u += EPI_WAVES) {
+        for (; u < sa.n_t; u += EW) {
             const float2 v = col[(size_t)u * sa.stride];
             acc.x += v.x;
             acc.y += v.y;
@@ -1592,13 +1591,13 @@ __global__ __launch_bounds__(EPI_BLOCK) void sfm_sym_epilogue_kernel(const TickA
     if (a.en_ped) {
         int any_bad = 0;
 #pragma unroll
-        for (int w = 0; w < EPI_WAVES; ++w) any_bad |= s_bad[w];
+        for (int w = 0; w < EW; ++w) any_bad |= s_bad[w];
         exact = uniform(any_bad) != 0;
     }
 
     // 2. coincident pairs in this tile: recompute its rows with the exact ordered body (rare)
     if (exact) {
-        for (int p = wave; p < WAVE; p += EPI_WAVES) {
+        for (int p = wave; p < WAVE; p += EW) {
             const int ip = t * WAVE + p;
             if (ip >= i_end) break;
             const float4 si = a.pk_cur[ip];
@@ -1626,7 +1625,7 @@ __global__ __launch_bounds__(EPI_BLOCK) void sfm_sym_epilogue_kernel(const TickA
     // 4. lane-parallel epilogue for the 64 pedestrians of the tile
     float2 g = s_sum[0][lane];
 #pragma unroll
-    for (int w = 1; w < EPI_WAVES; ++w) { const float2 b = s_sum[w][lane]; g.x += b.x; g.y += b.y; }
+    for (int w = 1; w < EW; ++w) { const float2 b = s_sum[w][lane]; g.x += b.x; g.y += b.y; }
     if (exact) g = s_exact[lane];
     const float fpx = a.en_ped ? a.ped.negA * g.x : 0.f, fpy = a.en_ped ? a.ped.negA * g.y : 0.f;
     float fbx = 0.f, fby = 0.f, fsx = 0.f, fsy = 0.f, fdx = 0.f, fdy = 0.f;
@@ -1840,16 +1839,25 @@ hipError_t launch_strip_bounds(const float4* box, const float* vmax, int n_t, in
     return hipGetLastError();
 }
 
-hipError_t launch_sym_epilogue(bool rad, const TickArgs& a, const SymArgs& sa, hipStream_t st) {
-    if (a.N <= 0) return hipSuccess;
+template <bool RAD, int EW>
+static void launch_sym_epilogue_t(const TickArgs& a, const SymArgs& sa, hipStream_t st) {
     TickArgs b = a;
     SymArgs sb = sa;
     b.adv.block0 = sa.t_hi - sa.t_lo;
-    const int extra = a.adv.M > 0 ? (a.adv.M + EPI_WAVES - 1) / EPI_WAVES : 0;
-    const int sched = sa.cost ? 1 : 0;             // scheduled lite cutoff: one more workgroup deals the next tick's order
+    const int extra = a.adv.M > 0 ? (a.adv.M + EW - 1) / EW : 0;
+    const int sched = (sa.cost && EW == EPI_WAVES) ? 1 : 0;   // scheduled lite cutoff: one more workgroup deals the next tick's order
     sb.sched_block = sched ? sa.t_hi - sa.t_lo + extra : -1;
-    if (rad) hipLaunchKernelGGL((sfm_sym_epilogue_kernel<true>), dim3(sa.t_hi - sa.t_lo + extra + sched), dim3(EPI_BLOCK), 0, st, b, sb);
-    else hipLaunchKernelGGL((sfm_sym_epilogue_kernel<false>), dim3(sa.t_hi - sa.t_lo + extra + sched), dim3(EPI_BLOCK), 0, st, b, sb);
+    hipLaunchKernelGGL((sfm_sym_epilogue_kernel<RAD, EW>), dim3(sa.t_hi - sa.t_lo + extra + sched), dim3(EW * WAVE), 0, st, b, sb);
+}
+
+// 16 waves per tile for small and mid-sized crowds (one dependent round of slab-row loads); from 1024 tiles on there are
+// plenty of workgroups and 4 waves per tile measured 2 % better on the c5 tick (the dealer of the scheduled lite cutoff, a
+// mid-sized-crowd feature, needs the 16-wave form).
+hipError_t launch_sym_epilogue(bool rad, const TickArgs& a, const SymArgs& sa, hipStream_t st) {
+    if (a.N <= 0) return hipSuccess;
+    const bool thin = sa.n_t >= 1024 && !sa.cost;
+    if (rad) { if (thin) launch_sym_epilogue_t<true, 4>(a, sa, st); else launch_sym_epilogue_t<true, EPI_WAVES>(a, sa, st); }
+    else { if (thin) launch_sym_epilogue_t<false, 4>(a, sa, st); else launch_sym_epilogue_t<false, EPI_WAVES>(a, sa, st); }
     return hipGetLastError();
 }
 
