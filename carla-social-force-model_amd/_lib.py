@@ -14,7 +14,7 @@ import numpy as np
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SFM_LIB_PATH") or os.path.join(PKG_DIR, "libsfm_hip.so")   # (the override is for A/B builds of the kernels)
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 FORCE_NAMES = ("acceleration_force", "pedestrian_force", "border_force",
                "static_obstacle_force", "dynamic_obstacle_force")

@@ -1807,7 +1807,8 @@ hipError_t launch_sym_pair(bool rad, const TickArgs& a, const SymArgs& sa, hipSt
         // a resident grid takes contiguous runs of the list: a few times more workgroups than fit at once (8 per CU), short runs
         // interleave better with the geometry kernel's workgroups and even out the tail; measured best 4x at 256 tiles, 16x from
         // 1024 tiles on
-        const int rounds = std::min(16, std::max(2, sa.n_t / 64));
+        static const int rounds_ov = getenv("SFM_ROUNDS") ? atoi(getenv("SFM_ROUNDS")) : 0;      // A/B only
+        const int rounds = rounds_ov > 0 ? rounds_ov : std::min(16, std::max(2, sa.n_t / 64));
         grid = sa.cost ? dim3(sym_item_count(sa.n_t)) : dim3(256 * 8 * rounds);    // scheduled: one dealt item per workgroup
     }
     const bool cut = sa.vmax != nullptr;           // list or lite cutoff: the per-step reach test is on as well

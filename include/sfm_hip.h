@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SFM_ABI_VERSION 1
+#define SFM_ABI_VERSION 2   /* 2: + sfm_tick_begin / sfm_tick_end, sfm_set_partition, sfm_get_pair_work (additions only) */
 
 typedef struct SfmHandle SfmHandle;
 
