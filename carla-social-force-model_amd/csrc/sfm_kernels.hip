@@ -462,12 +462,14 @@ __device__ __forceinline__ int geo_find(const TickArgs& a, const GeoLane& me, co
     return n_found;
 }
 
-template <bool RAD>
-__global__ __launch_bounds__(GEO_BLOCK, 8) void sfm_geometry_kernel(const TickArgs a) {   // 8 waves per SIMD = 64 VGPRs: two workgroups per CU
-    __shared__ float2 s_row[GEO_WAVES][WAVE];
-    __shared__ float s_acc[GEO_WAVES][6][WAVE];
-    __shared__ GeoItem s_item[GEO_WAVES][GEO_ITEMS];
-    __shared__ int s_count[GEO_WAVES];
+// GW waves per tile: 16 for up to 1023 tiles (two workgroups per CU: 64 VGPRs, 64 KB of LDS each); 8 from 1024 tiles on --
+// a workgroup's life is a chain of memory round trips, not work, so four thinner workgroups per CU beat two fat ones there.
+template <bool RAD, int GW>
+__global__ __launch_bounds__(GW * WAVE, 8) void sfm_geometry_kernel(const TickArgs a) {
+    __shared__ float2 s_row[GW][WAVE];
+    __shared__ float s_acc[GW][6][WAVE];
+    __shared__ GeoItem s_item[GW][GEO_ITEMS];
+    __shared__ int s_count[GW];
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = uniform((int)(threadIdx.x >> 6));
     unsigned long long st0 = 0, st1 = 0, st2 = 0;
@@ -507,7 +509,7 @@ __global__ __launch_bounds__(GEO_BLOCK, 8) void sfm_geometry_kernel(const TickAr
 
     // ---- phase 1: find
     const int slice = blockIdx.y;                                      // small crowds: the tile's polylines are split over
-    const int gwave = slice * GEO_WAVES + wave, n_gwaves = GEO_WAVES * (int)gridDim.y;   // gridDim.y workgroups
+    const int gwave = slice * GW + wave, n_gwaves = GW * (int)gridDim.y;   // gridDim.y workgroups
     const int n_found = geo_find<RAD, false>(a, me, tb, s_item[wave], row, lane, gwave, n_gwaves, f);
     if (lane == 0) s_count[wave] = min(n_found, GEO_ITEMS);
     __syncthreads();
@@ -518,9 +520,9 @@ __global__ __launch_bounds__(GEO_BLOCK, 8) void sfm_geometry_kernel(const TickAr
         int w = 0, first = 0, cnt = s_count[0];                       // items [first, first + cnt) belong to list w
         int total = 0;
 #pragma unroll
-        for (int q = 0; q < GEO_WAVES; ++q) total += s_count[q];
+        for (int q = 0; q < GW; ++q) total += s_count[q];
         total = uniform(total);
-        for (int j = wave; j < total; j += GEO_WAVES) {
+        for (int j = wave; j < total; j += GW) {
             while (j >= first + cnt) { first += cnt; ++w; cnt = s_count[w]; }
             const GeoItem it = s_item[uniform(w)][uniform(j - first)];
             GeoItem u = it;
@@ -539,7 +541,7 @@ __global__ __launch_bounds__(GEO_BLOCK, 8) void sfm_geometry_kernel(const TickAr
     if (wave < 6 && me.live) {                                         // wave w finishes component w
         float v = 0.0f;
 #pragma unroll
-        for (int w = 0; w < GEO_WAVES; ++w) v += s_acc[w][wave][lane];
+        for (int w = 0; w < GW; ++w) v += s_acc[w][wave][lane];
         if (wave >= 4) v *= a.dyn.negA;
         else if (wave >= 2) v *= a.stat.negA;
         a.geo[((size_t)slice * 6 + wave) * a.N_pad + i] = v;
@@ -1769,8 +1771,15 @@ hipError_t launch_geometry(bool rad, const TickArgs& a, hipStream_t st) {
     const int n_local = a.i_end - a.i_begin;
     if (n_local <= 0) return hipSuccess;
     const int grid = ((a.i_end + WAVE - 1) >> 6) - (a.i_begin >> 6);      // tiles overlapping the shard
-    if (rad) hipLaunchKernelGGL((sfm_geometry_kernel<true>), dim3(grid, a.geo_slices), dim3(GEO_BLOCK), 0, st, a);
-    else hipLaunchKernelGGL((sfm_geometry_kernel<false>), dim3(grid, a.geo_slices), dim3(GEO_BLOCK), 0, st, a);
+    static const int gw_ov = getenv("SFM_GEO_WAVES") ? atoi(getenv("SFM_GEO_WAVES")) : 0;        // A/B only
+    const bool thin = gw_ov ? gw_ov == 8 : grid >= 1024;
+    if (thin) {
+        if (rad) hipLaunchKernelGGL((sfm_geometry_kernel<true, 8>), dim3(grid, a.geo_slices), dim3(8 * WAVE), 0, st, a);
+        else hipLaunchKernelGGL((sfm_geometry_kernel<false, 8>), dim3(grid, a.geo_slices), dim3(8 * WAVE), 0, st, a);
+    } else {
+        if (rad) hipLaunchKernelGGL((sfm_geometry_kernel<true, GEO_WAVES>), dim3(grid, a.geo_slices), dim3(GEO_BLOCK), 0, st, a);
+        else hipLaunchKernelGGL((sfm_geometry_kernel<false, GEO_WAVES>), dim3(grid, a.geo_slices), dim3(GEO_BLOCK), 0, st, a);
+    }
     return hipGetLastError();
 }
 
