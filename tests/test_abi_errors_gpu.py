@@ -44,6 +44,15 @@ def test_argument_and_state_errors():
         assert lib.sfm_download_modes(h, None, None, None) == -3                                  # FSM not set
         assert lib.sfm_run_recorded(h, 5, 0, 0, None, 0, None) == -1
         assert lib.sfm_tick(h, 4) == 0 and lib.sfm_download_forces(h, 5, f, f, None) == 0
+        # round-2 entry points
+        bnd = np.array([0, 64, 32], np.int32)
+        assert lib.sfm_set_partition(h, 2, 1, bnd.ctypes.data_as(_lib._I)) == -1 and "non-decreasing" in _err(lib, h)
+        assert lib.sfm_set_partition(h, 5, 5, None) == -1 and "16" in _err(lib, h)
+        assert lib.sfm_set_partition(h, 2, 0, None) == -1
+        assert lib.sfm_set_partition(h, 0, 0, None) == 0
+        items, terms = C.c_longlong(0), C.c_longlong(0)
+        assert lib.sfm_get_pair_work(h, C.byref(items), C.byref(terms)) == -3 and "symmetric" in _err(lib, h)   # one pedestrian: ordered kernel
+        assert lib.sfm_tick_begin(h, 0) == 0 and lib.sfm_tick_end(h, 0) == 0                      # not a shard: begin is a no-op, end the whole tick
     finally:
         assert lib.sfm_destroy(h) == 0
     assert lib.sfm_destroy(None) == 0
