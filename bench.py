@@ -261,6 +261,13 @@ def main():
     times = timed_windows(st.step, barrier, reduce_max, args.steps, args.windows, args.min_seconds)
     elapsed = statistics.median(times)
 
+    # the crowd must still be a crowd: a NaN or a runaway pedestrian anywhere in this rank's rows fails the run loudly
+    _loc, _vel, _ = eng.engine.state()
+    _own = ~np.isnan(_vel[:, 0]) if world > 1 else np.ones(sc.n, bool)
+    _speed = np.linalg.norm(_vel[_own, :2], axis=1)
+    if not (np.isfinite(_loc[_own, :2]).all() and np.isfinite(_speed).all() and _speed.max() <= 1.3 * float(sc.target_speed.max()) * 1.001):
+        raise SystemExit(f"bench.py: state check failed after the timed run on rank {rank} (non-finite or over-speed pedestrians)")
+
     # whole tick on the launch stream (HIP events, no collective in between) ...
     reps = min(max(args.steps, 1), 200 if sc.n <= 16384 else 10)
     eng.engine.run(reps, redraw=True)
