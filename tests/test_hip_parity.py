@@ -308,10 +308,12 @@ def test_property_checks_at_baseline_size():
 
 # ceilings on what the conditioned tolerance of _parity.check_force was allowed to absorb at full size (measured values in
 # profiles/r02_full_size_parity_diagnostics.txt; a regression in the kernels shows up here before it can hide in the
-# conditioning): plain max|dF| / max|F|, 99th percentile of the per-pedestrian |dF| / |F|, mean conditioning weight per
+# conditioning): plain max|dF| / max|F|, 99th percentile of the per-pedestrian |dF| / |F| (fresh states), mean conditioning weight per
 # pedestrian, pedestrians that got a discontinuity allowance at all (its size relative to the scale is printed, not bounded:
 # a sign(theta) flip of a dominant lateral term is legitimately of order one)
-FULL_SIZE_CEILINGS = {"plain_rel": 5e-6, "row_rel_p99": 1e-5, "max_amp": 1.0, "n_expo": 200}   # n_expo: of 768 sampled rows x 2 rounds
+FULL_SIZE_CEILINGS = {"plain_rel": 1e-5, "max_amp": 1.0, "n_expo": 300}   # n_expo: of 768 sampled rows x 3 rounds
+ROW_REL_P99_FRESH = 1e-5      # ticks 1 and 4 only: by tick 134 the crowd is near equilibrium -- the goal force balances the repulsion,
+                              # |F_i| is a small difference of large terms -- and a per-pedestrian |dF_i| / |F_i| stops measuring the kernels
 
 
 @pytest.mark.parametrize("name", ["c2", "c3", "c4", "c5"])
@@ -319,8 +321,9 @@ def test_baseline_configs_at_full_size_row_samples(name):
     """BASELINE configs 2-5 at their full sizes, in the configuration bench.py runs them (c2: acceleration + pedestrian force
     through the symmetric kernel; c3-c5: spatial packing, tile cutoff, two-level list at c5, geometry kernel): the summed
     force and v' of three row blocks -- first, middle, last in the caller's order, i.e. scattered over the internal tiles --
-    against the C oracle, after one tick and, for the state the device reached by itself, after 3 more ticks
-    (re-synchronised: the oracle starts from the device's state).  Prints and bounds what the tolerance leaned on."""
+    against the C oracle, after one tick and, for the states the device reached by itself, at tick 4 and at tick 134
+    (re-synchronised: the oracle starts from the device's state; two device re-packs lie in between).  Prints and bounds
+    what the tolerance leaned on."""
     sc, forces = scenarios.baseline_scenario(name)
     cfg = default_sfm_config(forces)
     prm = O.OracleParams.from_config(cfg)
@@ -335,7 +338,7 @@ def test_baseline_configs_at_full_size_row_samples(name):
         eng.upload_state(sc.loc, sc.vel, sc.waypoint, sc.target_speed, sc.radius, None)
         loc, vel, wp3 = sc.loc, sc.vel, sc.waypoint
         worst = {}
-        for rnd in range(2):
+        for rnd in range(3):
             geom = O.Geometry(sc.borders, sc.border_centers, sc.border_lengths, sc.static_obstacles, sc.dynamic_obstacles,
                               sc.dynamic_vel)
             eng.tick(integrate=True, record=True)
@@ -350,15 +353,20 @@ def test_baseline_configs_at_full_size_row_samples(name):
                 vw = P.check_velocity(v[r[0]:r[1]], v_new, expo, 0.05)
                 d = P.diagnostics(F[r[0]:r[1]], total, absum, plain, expo)
                 d["v_rel"] = vw
+                if rnd == 2:
+                    d["row_rel_p99_tick134"] = d.pop("row_rel_p99")
                 for k, val in d.items():
                     worst[k] = max(worst.get(k, 0), val)
-            if rnd == 0:
-                eng.run(2, redraw=False)                               # the device carries on by itself ...
-                loc, vel, wp = eng.state()                             # ... and the oracle restarts from where it got to
+            if rnd < 2:
+                # the device carries on by itself -- 2 ticks, then 130 more (two device re-packs, carried boxes, waypoint redraws) --
+                # and the oracle restarts from where it got to
+                eng.run(2 if rnd == 0 else 130, redraw=rnd == 1)
+                loc, vel, wp = eng.state()
                 wp3 = np.zeros_like(loc); wp3[:, :2] = wp
         print(f"\nfull-size parity {name} ({eng.kernel_variant()}): " + "  ".join(f"{k}={v:.3g}" for k, v in sorted(worst.items())))
         for k, ceil in FULL_SIZE_CEILINGS.items():
             assert worst[k] <= ceil, f"{name}: {k} = {worst[k]:.3g} above its ceiling {ceil}"
+        assert worst["row_rel_p99"] <= ROW_REL_P99_FRESH
         assert worst["v_rel"] <= P.RTOL
     finally:
         eng.close()
