@@ -274,7 +274,8 @@ def main():
     ev_ms, ev_ticks, ev_launches = eng.engine.timing()
     tick_us = ev_ms * 1e3 / max(ev_ticks, 1)
     variant = eng.engine.kernel_variant()
-    sym = "sym" in variant
+    fused = "fused" in variant                   # one launch per tick: the pair kernel with the integration as its prologue
+    sym = "sym" in variant or fused
     pair_items = pair_terms = None
     if sym and "pedestrian_force" in forces:
         pair_items, pair_terms = eng.engine.pair_work()             # of the last tick above
@@ -293,9 +294,9 @@ def main():
             pair_items, pair_terms = e2.engine.pair_work()
         e2.close()
         state_note = f"{PMC_STATE_TICKS[name]} ticks after the upload (the state of the committed counter passes)"
-    dominant = "sfm_pair_sym_kernel" if sym else "sfm_tick_kernel"
+    dominant = "sfm_fused_tick_kernel" if fused else "sfm_pair_sym_kernel" if sym else "sfm_tick_kernel"
     alg = 16.0 * (hi - lo) * (sc.n - 1.0) if "pedestrian_force" in forces else 0.0
-    if not sym:
+    if not sym or fused:
         alg += 44.0 * (hi - lo)                      # the ordered kernel also reads / writes the own rows
     alg_tick = algorithmic_bytes(sc, forces, hi - lo)
     alg_gbs = alg / (kernel_us * 1e-6) / 1e9

@@ -20,6 +20,7 @@ hipError_t launch_arrived(const float4* pk, const float4* own, int N, float thr2
 hipError_t launch_sym_list(const TickArgs& a, const SymArgs& sa, hipStream_t st, int partners = 0, bool count_is_zero = false);
 hipError_t launch_sym_pair(bool rad, const TickArgs& a, const SymArgs& sa, hipStream_t st);
 hipError_t launch_sym_epilogue(bool rad, const TickArgs& a, const SymArgs& sa, hipStream_t st);
+hipError_t launch_fused_tick(bool rad, const TickArgs& a, const FusedArgs& f, hipStream_t st);
 hipError_t launch_schedule(const int* cost, int n_t, uint32_t* work, int* count, hipStream_t st);
 int sym_item_count(int n_t);
 hipError_t launch_strip_bounds(const float4* box, const float* vmax, int n_t, int tps, int n_strips, float4* sbox, float* svmax,
@@ -144,6 +145,19 @@ struct SfmHandle {
     bool perm_stale = false;
     float r_max = 0.f;
     bool used_sym = false;
+    // fused tick (sfm_fused_tick_kernel): one launch per tick inside sfm_run for a whole planar crowd without border / obstacle forces
+    float2* fslab = nullptr;               // [2][n_g][N_pad] partial forces, ping-pong across launches
+    size_t fslab_cap = 0;
+    float4* own_alt = nullptr;             // the waypoints ping-pong with the state
+    int own_alt_cap = 0;
+    int fused_mode = -1;                   // SFM_FUSED=0: always the two-kernel tick (A/B, tests)
+    bool used_fused = false;
+    // A fused run ends with the partial forces of its final state already in fslab: the next sfm_run / sfm_tick carries on from
+    // there (one launch per tick, no start-up launch) provided NOTHING else was called on the handle in between -- api_seq counts
+    // the entry points that went through bind(), the few that do not reset carry_ok themselves.
+    unsigned long long api_seq = 0, carry_seq = 0;
+    bool carry_ok = false;
+    int carry_sl = 0;
     bool last_list = false;                // the last symmetric tick ran from the tile-pair list (cutoff on)
     // scheduled lite cutoff (mid-sized whole crowds): per-item step counts of the last tick and whether `work` holds a dealt order
     int* cost = nullptr;
@@ -203,6 +217,7 @@ static int fail(SfmHandle* h, int code, const char* msg) {
 
 static int bind(SfmHandle* h) {
     if (!h) return SFM_ERR_INVALID;
+    ++h->api_seq;
     hipError_t e = hipSetDevice(h->device);
     if (e != hipSuccess) { h->err = std::string("hipSetDevice: ") + hipGetErrorString(e); return SFM_ERR_HIP; }
     return SFM_OK;
@@ -301,6 +316,8 @@ int sfm_create(const SfmParams* params, int device_id, SfmHandle** out) {
     if (ov) h->split_mode = atoi(ov);
     ov = getenv("SFM_GEO_AHEAD");
     if (ov) h->geo_ahead_mode = atoi(ov);
+    ov = getenv("SFM_FUSED");
+    if (ov) h->fused_mode = atoi(ov);
     ov = getenv("SFM_SCHED");
     if (ov) h->sched_mode = atoi(ov);
     ov = getenv("SFM_REORDER");
@@ -369,6 +386,8 @@ int sfm_destroy(SfmHandle* h) {
     if (h->dyn_local) hipFree(h->dyn_local);
     if (h->dyn_rot) hipFree(h->dyn_rot);
     if (h->slab) hipFree(h->slab);
+    if (h->fslab) hipFree(h->fslab);
+    if (h->own_alt) hipFree(h->own_alt);
     if (h->tile_flag) hipFree(h->tile_flag);
     for (void* q : {(void*)h->f_mode, (void*)h->f_target, (void*)h->f_initial, (void*)h->f_crossing, (void*)h->f_margin,
                     (void*)h->f_next, (void*)h->f_off, (void*)h->f_cursor, (void*)h->f_xy, (void*)h->f_cross})
@@ -401,12 +420,14 @@ int sfm_set_params(SfmHandle* h, const SfmParams* params) {
     const char* why = nullptr;
     if (!check_params(params, &why)) return fail(h, SFM_ERR_INVALID, why);
     drop_geo_ahead(h);
+    h->carry_ok = false;
     h->prm = *params;
     return SFM_OK;
 }
 
 int sfm_set_stream(SfmHandle* h, void* hip_stream) {
     if (!h) return SFM_ERR_INVALID;
+    h->carry_ok = false;
     h->stream = reinterpret_cast<hipStream_t>(hip_stream);
     return SFM_OK;
 }
@@ -612,6 +633,8 @@ int sfm_upload_state(SfmHandle* h, int N, const float* x, const float* y, const 
         for (int b = 0; b < 2; ++b) HIP_TRY(h, dev_realloc(h->pk[b], (size_t)n_pad));
         for (int b = 0; b < 2; ++b) HIP_TRY(h, dev_realloc(h->zv[b], (size_t)n_pad));
         HIP_TRY(h, dev_realloc(h->own, (size_t)n_pad));
+        HIP_TRY(h, dev_realloc(h->own_alt, 0));      // (the fused tick's twin of own: re-made at the new size when next needed)
+        h->own_alt_cap = 0;
         HIP_TRY(h, dev_realloc(h->radius, (size_t)n_pad));
         HIP_TRY(h, dev_realloc(h->crossing, (size_t)n_pad));
         HIP_TRY(h, dev_realloc(h->arrived, (size_t)n_pad));
@@ -813,6 +836,7 @@ int sfm_set_shard(SfmHandle* h, int i_begin, int i_end) {
     if (!h) return SFM_ERR_INVALID;
     if (i_begin < 0 || i_end < i_begin || i_end > h->N) return fail(h, SFM_ERR_INVALID, "shard out of range");
     drop_geo_ahead(h);
+    h->carry_ok = false;
     h->i_begin = i_begin;
     h->i_end = i_end;
     return SFM_OK;
@@ -820,6 +844,7 @@ int sfm_set_shard(SfmHandle* h, int i_begin, int i_end) {
 
 int sfm_set_partition(SfmHandle* h, int gx, int gy, const int32_t* bounds) {
     if (!h) return SFM_ERR_INVALID;
+    h->carry_ok = false;
     if (gx < 0 || gy < 0 || (gx == 0) != (gy == 0) || gx * gy > MAX_BLOCKS) return fail(h, SFM_ERR_INVALID, "partition must be gx x gy blocks, at most 16");
     const int G = gx * gy;
     if (bounds) {
@@ -835,6 +860,7 @@ int sfm_set_partition(SfmHandle* h, int gx, int gy, const int32_t* bounds) {
 
 int sfm_set_waypoint_stream(SfmHandle* h, uint32_t seed, float world_side, float arrive_threshold) {
     if (!h) return SFM_ERR_INVALID;
+    h->carry_ok = false;
     h->seed = seed;
     h->world_side = world_side;
     h->arrive_thr = arrive_threshold;
@@ -988,9 +1014,62 @@ static SymArgs make_sym_args(const SfmHandle* h, const TickArgs& a, int tps, int
 constexpr int PHASE_FULL = 0, PHASE_BEGIN = 1, PHASE_END = 2;
 constexpr int LIST_ALL = 0, LIST_OWN = 1, LIST_REMOTE = 2;        // = PARTNERS_* of sfm_kernels.hip
 
+// Fused tick (sfm_fused_tick_kernel): one launch -- mode 0 evaluates the stored state's pairs, mode 1 integrates the
+// state by one tick, stores it and evaluates the new state's pairs.  *sl = which half of fslab this launch writes.
+static int fused_launch(SfmHandle* h, uint32_t flags, int mode, int* sl) {
+    const int n_g = (h->n_t + 1) / 2;
+    const size_t rows = (size_t)n_g * (size_t)h->N_pad;
+    TickArgs a;
+    fill_args(h, a, flags);
+    static const bool blocked_ok = !(getenv("SFM_FUSED_BLOCKED") && atoi(getenv("SFM_FUSED_BLOCKED")) == 0);      // A/B only
+    const FusedArgs f{h->fslab + (size_t)(*sl ^ 1) * rows, h->fslab + (size_t)*sl * rows, h->own, h->own_alt, n_g, h->n_t, h->dpp_dir,
+                      (blocked_ok && n_g % 8 == 0) ? 1 : 0, mode};
+    HIP_TRY(h, launch_fused_tick(h->rad, a, f, h->stream));
+    if (mode != 0) { h->cur ^= 1; std::swap(h->own, h->own_alt); }
+    *sl ^= 1;
+    return SFM_OK;
+}
+
+static int fused_reserve(SfmHandle* h) {
+    const size_t need = (size_t)2 * (size_t)((h->n_t + 1) / 2) * (size_t)h->N_pad;
+    if (need > h->fslab_cap) { HIP_TRY(h, dev_realloc(h->fslab, need)); h->fslab_cap = need; }
+    if (h->own_alt_cap < h->cap) { HIP_TRY(h, dev_realloc(h->own_alt, (size_t)h->cap)); h->own_alt_cap = h->cap; }   // same size as own: they swap
+    return SFM_OK;
+}
+
+// `ticks` ticks of a whole planar crowd with acceleration + pedestrian force only, one launch each.  `carry`: the previous call on
+// this handle was such a run too, its last launch left the partial forces of the current state in fslab; otherwise one launch
+// in front evaluates them.  Either way the run ends with state AND partial forces current.
+static int run_fused(SfmHandle* h, int ticks, uint32_t flags, bool carry) {
+    int rc = fused_reserve(h);
+    if (rc) return rc;
+    snprintf(h->variant, sizeof(h->variant), "sfm_fused_tick_kernel");
+    HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+    int sl = carry ? h->carry_sl : 0;
+    if (!carry) rc = fused_launch(h, flags, 0, &sl);
+    for (int t = 0; t < ticks && rc == SFM_OK; ++t) rc = fused_launch(h, flags, 1, &sl);
+    if (rc) return rc;
+    HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
+    h->ticks_since_sort += ticks;
+    h->used_fused = true;
+    h->carry_ok = true;
+    h->carry_seq = h->api_seq;
+    h->carry_sl = sl;
+    h->last_list = h->last_sched = h->last_split = false;
+    h->boxes_valid = false;
+    h->count_zeroed = false;
+    h->timed_ticks = ticks;
+    h->timed_launches = ticks + (carry ? 0 : 1);
+    h->timing_valid = true;
+    h->rec_valid = false;
+    return SFM_OK;
+}
+
 static int run_ticks(SfmHandle* h, int ticks, uint32_t flags, int phase = PHASE_FULL) {
     int rc = bind(h);
     if (rc) return rc;
+    const bool carry = h->carry_ok && h->api_seq == h->carry_seq + 1;     // the call before this one was a fused run, nothing in between
+    h->carry_ok = false;
     if (ticks < 0) return fail(h, SFM_ERR_INVALID, "ticks < 0");
     if (phase == PHASE_END && h->begin_done) flags = h->begin_flags;
     if (phase != PHASE_END) h->timing_valid = false;
@@ -1004,12 +1083,13 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags, int phase = PHASE_
     strip_shape(h, &tps, &n_strips);
     // symmetric path: planar crowd, the whole of it on this handle or a tile-aligned shard; auto mode wants >= 4 tiles
     const size_t need = (size_t)h->n_t * (size_t)slab_stride(h->n_t);
-    bool order_pays, list_cut;                      // compact tiles only matter to the tile cutoff and the geometry kernel
+    bool order_pays, list_cut, plain;               // compact tiles only matter to the tile cutoff and the geometry kernel
     {
         TickArgs probe;
         fill_args(h, probe, flags);
         order_pays = probe.geo != nullptr || probe.tile_box != nullptr;
         list_cut = probe.tile_box != nullptr && !probe.lite;
+        plain = probe.geo == nullptr && probe.tile_box == nullptr && probe.adv.M == 0;
     }
     // a shard can use it too when its rows are whole tiles and the tile-pair list is on: pairs with a tile of another
     // rank are then evaluated one-sided by both ranks
@@ -1023,6 +1103,12 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags, int phase = PHASE_
     if (sym) snprintf(h->variant, sizeof(h->variant), "sfm_pair_sym_kernel+sfm_sym_epilogue_kernel");
     else snprintf(h->variant, sizeof(h->variant), "sfm_tick_kernel<%d,%s,%s,%d>", ipw, h->z3 ? "true" : "false",
                   h->rad ? "true" : "false", team);
+    h->used_fused = false;
+    // ---- several ticks of a whole crowd with nothing but the acceleration and pedestrian forces: one launch per tick
+    //      (a single tick only when it carries on from a fused run: on its own it would be two launches again)
+    if (sym && whole && plain && phase == PHASE_FULL && (ticks >= 2 || carry) && h->fused_mode != 0 && (flags & SFM_TICK_INTEGRATE) &&
+        !(flags & SFM_TICK_RECORD_FORCES) && !h->fsm_on && h->debug_steps < 0 && !h->stamps && h->n_t >= 4)
+        return run_fused(h, ticks, flags, carry);
     // ---- split tick of a shard: what needs only this rank's rows first (sfm_tick_begin), the rest once the exchange is in
     //      (sfm_tick_end).  Anything else: sfm_tick_begin does nothing and sfm_tick_end runs the whole tick.
     if (phase == PHASE_BEGIN) {
@@ -1185,6 +1271,39 @@ int sfm_profile_dominant_kernel(SfmHandle* h, int reps, float* avg_us) {
     if (rc) return rc;
     if (reps <= 0 || !avg_us) return fail(h, SFM_ERR_INVALID, "reps <= 0 or avg_us is NULL");
     if (h->N == 0 || !h->pk[0]) return fail(h, SFM_ERR_STATE, "no state uploaded");
+    if (h->used_fused) {
+        // the last sfm_run took the fused tick: its launches integrate, so they are timed for real on a saved state -- `reps`
+        // mid-run launches (integrate + pairs) between the events -- and the state is put back afterwards
+        const size_t np_ = (size_t)h->N_pad;
+        float4 *pk_keep = nullptr, *own_keep = nullptr;
+        uint32_t* draws_keep = nullptr;
+        HIP_TRY(h, dev_realloc(pk_keep, np_)); HIP_TRY(h, dev_realloc(own_keep, np_)); HIP_TRY(h, dev_realloc(draws_keep, np_));
+        HIP_TRY(h, hipMemcpyAsync(pk_keep, h->pk[h->cur], sizeof(float4) * np_, hipMemcpyDeviceToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(own_keep, h->own, sizeof(float4) * np_, hipMemcpyDeviceToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(draws_keep, h->draws, sizeof(uint32_t) * np_, hipMemcpyDeviceToDevice, h->stream));
+        rc = fused_reserve(h);
+        const uint32_t fl = SFM_TICK_INTEGRATE | SFM_TICK_REDRAW_WAYPOINTS;
+        int sl = 0;
+        if (!rc) rc = fused_launch(h, fl, 0, &sl);
+        if (!rc) rc = fused_launch(h, fl, 1, &sl);
+        if (rc) return rc;
+        HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+        for (int r = 0; r < reps && rc == SFM_OK; ++r) rc = fused_launch(h, fl, 1, &sl);
+        if (rc) return rc;
+        HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(h->pk[h->cur], pk_keep, sizeof(float4) * np_, hipMemcpyDeviceToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(h->own, own_keep, sizeof(float4) * np_, hipMemcpyDeviceToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(h->draws, draws_keep, sizeof(uint32_t) * np_, hipMemcpyDeviceToDevice, h->stream));
+        HIP_TRY(h, hipEventSynchronize(h->ev1));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        float ms = 0.f;
+        HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+        *avg_us = ms * 1000.0f / (float)reps;
+        hipFree(pk_keep); hipFree(own_keep); hipFree(draws_keep);
+        h->carry_ok = false;
+        h->timing_valid = false;
+        return SFM_OK;
+    }
     rc = run_ticks(h, 1, 0);                       // settles the launch shape (and the cutoff work list) ...
     if (rc) return rc;
     h->cur ^= 1;                                   // ... and steps back: the probe must not advance the state
@@ -1393,17 +1512,20 @@ int sfm_download_draw_counts(SfmHandle* h, uint32_t* counts) {
 
 void* sfm_packed_state_ptr(SfmHandle* h, int* n_pad) {
     if (!h) return nullptr;
+    h->carry_ok = false;                           // the caller may write through the pointer
     if (n_pad) *n_pad = h->N_pad;
     return h->pk[h->cur];
 }
 
 void* sfm_packed_z_ptr(SfmHandle* h) {
     if (!h || !h->z3) return nullptr;
+    h->carry_ok = false;                           // the caller may write through the pointer
     return h->zv[h->cur];
 }
 
 void* sfm_row_data_ptr(SfmHandle* h, int which, int* bytes_per_row) {
     if (!h || which < 0 || which > 1) return nullptr;
+    h->carry_ok = false;                           // the caller may write through the pointer
     if (bytes_per_row) *bytes_per_row = which == 0 ? (int)sizeof(float4) : (int)sizeof(uint32_t);
     return which == 0 ? (void*)h->own : (void*)h->draws;
 }

@@ -141,6 +141,24 @@ struct SymArgs {
     int zero_count;      // epilogue launch: 1 = leave *work_count at 0 for the next tick's list kernel (saves its memset)
 };
 
+// Fused tick of a whole planar crowd with the acceleration and pedestrian forces only (sfm_fused_tick_kernel):
+// ONE launch per tick inside sfm_run.  Tiles go in groups of two; a workgroup owns one unordered group pair, first integrates its own
+// four tiles from the previous launch's partial forces (every workgroup that needs a tile recomputes it -- the same arithmetic on
+// the same operands, so all agree bit for bit; the workgroup of the group's diagonal item is the one that stores it), then
+// evaluates its tile pairs of the NEW state.  State, waypoints and partial forces ping-pong between launches.
+struct FusedArgs {
+    const float2* slab_prev;  // [n_g][N_pad]: slab[r][i] = -A-less force on pedestrian i from the pedestrians of group r, previous state
+    float2* slab_next;        // the same for the state this launch integrates to
+    const float4* own_cur;    // {wx, wy, target_speed, radius} going with pk_cur
+    float4* own_next;
+    int n_g;                  // groups of two tiles
+    int n_t;
+    int dir;                  // as SymArgs::dir
+    int blocked;              // 1: XCD-aware order of the work items (n_g a multiple of 8)
+    int mode;                 // 0: the stored state is the state (nothing to integrate, nothing stored but slab_next): the launch in
+                              //    front of a run; 1: integrate by one tick, store, then the pairs of the new state
+};
+
 // Block-major packing for sharded runs (sfm_set_partition, sfm_reorder.hip): the row order is cut into gx columns by x, each
 // column into gy blocks by y -- block b = column * gy + position holds rows [bound[b], bound[b+1]) -- and every block is
 // strip-packed on its own, so a rank's contiguous row range is a compact rectangle of the map instead of a slab across it.

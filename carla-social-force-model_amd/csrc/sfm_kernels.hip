@@ -1703,6 +1703,306 @@ __global__ __launch_bounds__(EW * WAVE) void sfm_sym_epilogue_kernel(const TickA
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// fused tick: one launch per tick for a whole planar crowd with the acceleration and pedestrian forces only
+// ------------------------------------------------------------------------------------------------------
+// The two-kernel tick above spends 4.5 of its 19.5 us at N = 4096 on the epilogue launch and the two kernel boundaries around
+// it.  Here the epilogue of tick t is the PROLOGUE of tick t+1's pair kernel: tiles go in groups of two, a workgroup (8 waves)
+// owns one unordered pair of groups (GX, GY) = four tile pairs, or two diagonal groups.  It first integrates its own 256
+// pedestrians from the previous launch's partial forces (a column sum over n_g slab rows, split over the two halves of the
+// workgroup), keeps the new state in LDS, and then runs the systolic steps of sfm_pair_sym_kernel on it: every wave 32 steps.
+// A tile is integrated by every workgroup that needs it -- the same arithmetic on the same operands, hence the same bits --
+// and stored by the workgroup of its group's diagonal item.  No flag, no atomic, no fence: the only synchronisation is the
+// kernel boundary, and state / waypoints / partial forces ping-pong across it.  Grouping tiles by two halves the slab rows a
+// pedestrian's sum runs over (n_g = n_t / 2), which is what makes reading them in every workgroup affordable.
+// A coincident pair leaves a NaN in the sums of its two pedestrians, as in the two-kernel path: those rows are recomputed with
+// the exact body (by every workgroup that holds them).
+constexpr int GROUP = 2 * WAVE;                  // pedestrians per group of two tiles
+
+template <bool RAD, int NW>                      // NW waves per workgroup (8 or 16): 256 / NW systolic steps each
+__global__ __launch_bounds__(NW * WAVE) void sfm_fused_tick_kernel(const TickArgs a, const FusedArgs f) {
+    constexpr int PARTS = NW / 2;                // the slab rows are split over this many 128-thread parts
+    constexpr int SPW = 4 * WAVE / NW;           // systolic steps per wave
+    constexpr int D = NW / 8;                    // waves per diagonal tile
+    __shared__ float4 s_st[2 * GROUP];           // the workgroup's pedestrians in the state the pairs are evaluated on: GX then GY
+    __shared__ float s_rad[2 * GROUP];
+    __shared__ float2 s_q[PARTS][2 * GROUP];     // partial column sums
+    __shared__ float2 s_part[2 * GROUP];         // exact rows
+    __shared__ int s_badrow[2 * GROUP];
+    __shared__ int s_any;
+    __shared__ float2 s_fi[NW][WAVE];
+    __shared__ float2 s_fj[NW][WAVE];
+    const int tid = threadIdx.x;
+    const int lane = tid & (WAVE - 1);
+    const int wave = uniform(tid >> 6);
+    const int n_g = f.n_g, n_t = f.n_t;
+    const int half_up = (n_g + 1) >> 1;          // diagonal items pair group bx with group bx + half_up
+    // Work items, one per workgroup and no idle workgroup in the grid (the dispatcher deals workgroup w to CU w mod 256 whatever
+    // it holds, so a grid with holes leaves some CUs a whole workgroup more than others).
+    int GX, GY;
+    bool diag_item;
+    if (f.blocked) {
+        // n_g a multiple of 8: the groups go in four bands of s, and the workgroups that land on one XCD (w mod 8, observed on
+        // MI355X; nothing but speed depends on it) take their group pairs from one pair of bands -- XCDs 0-5 the six pairs of
+        // different bands (s x s workgroups each), XCDs 6 and 7 two bands' inner pairs each (s/2 diagonal items of neighbouring
+        // groups + s (s-1) / 2 pairs per band = s x s for two bands).  An XCD's L2 then fetches the column sums of 2 s groups
+        // instead of all 4 s: half the traffic across the fabric at the start of the launch.
+        const int s = n_g >> 2;
+        const int x = blockIdx.x & 7;
+        int k = blockIdx.x >> 3;
+        if (x < 6) {
+            const int I = x < 3 ? 0 : (x < 5 ? 1 : 2), J = x < 3 ? x + 1 : (x < 5 ? x - 1 : 3);
+            GX = I * s + k / s;
+            GY = J * s + k % s;
+            diag_item = false;
+        } else {
+            const int per_band = (s * s) >> 1;
+            const int I = 2 * (x - 6) + (k >= per_band ? 1 : 0);
+            if (k >= per_band) k -= per_band;
+            if (k < (s >> 1)) {
+                GX = I * s + 2 * k; GY = GX + 1;
+                diag_item = true;
+            } else {
+                int t = k - (s >> 1), u = 0;
+                while (t >= s - 1 - u) { t -= s - 1 - u; ++u; }      // triangular index -> (u, v), u < v < s
+                GX = I * s + u; GY = I * s + u + 1 + t;
+                diag_item = false;
+            }
+        }
+    } else {
+        // first the diagonal items (group bx with group bx + half_up), then the group pairs (bx, bx + shift) shift by shift; the
+        // last shift of an even n_g (antipodal pairs) has only its lower half
+        int shift = 0, bx = blockIdx.x;
+        if (bx >= half_up) {
+            const int id = bx - half_up;
+            shift = 1 + id / n_g;
+            bx = id - (shift - 1) * n_g;
+        }
+        GX = bx;
+        GY = bx + (shift == 0 ? half_up : shift);   // a diagonal item's second group may not exist (odd n_g): its waves idle
+        if (shift != 0 && GY >= n_g) GY -= n_g;
+        diag_item = shift == 0;
+    }
+
+    // ---- 1. the state of this launch: integrate the workgroup's 256 pedestrians from the previous launch's partial forces.
+    //      Every load of the prologue is issued before the first use of any (they come from other XCDs' writes: one round
+    //      trip, not several): own state first, then the column sums -- a thread takes two neighbouring pedestrians (16-B
+    //      loads) and 1/PARTS of the slab rows.
+    const bool integrate = f.mode != 0;
+    const int p = tid & (2 * GROUP - 1);         // pedestrian slot (the first 256 threads integrate)
+    const bool lower = tid < 2 * GROUP;
+    const int G = (p < GROUP) ? GX : GY;
+    const bool present = G < n_g;
+    const int i = G * GROUP + (p & (GROUP - 1)); // < N_pad whenever the group exists (N_pad is a multiple of four tiles)
+    const bool live = present && i < a.N;
+    float4 st = make_float4(0.f, 0.f, 0.f, 0.f), o = st;
+    uint32_t nd0 = 0, pid = 0;
+    if (present && lower) {
+        st = a.pk_cur[i];
+        if (live && integrate) {
+            o = f.own_cur[i];
+            if ((a.flags & 2u) && diag_item) { nd0 = a.draws[i]; pid = a.ids ? a.ids[i] : (uint32_t)i; }
+        }
+        if (RAD) s_rad[p] = a.radius[i];
+    }
+    if (tid == 0) s_any = 0;
+    {
+        const int pp = tid & (GROUP - 1);        // pedestrians 2 pp, 2 pp + 1 of the workgroup's 256
+        const int part = uniform(tid >> 7);
+        const int Gq = (2 * pp < GROUP) ? GX : GY;
+        const int i2 = Gq * GROUP + ((2 * pp) & (GROUP - 1));
+        float4 acc4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (integrate && a.en_ped && Gq < n_g && i2 < a.N) {
+            const float4* col = reinterpret_cast<const float4*>(f.slab_prev + i2);
+            const size_t stride4 = (size_t)a.N_pad / 2;
+            const int per = (n_g + PARTS - 1) / PARTS;
+            const int r1 = min(n_g, (part + 1) * per);
+            for (int r0 = part * per; r0 < r1; r0 += 8) {
+                float4 v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = (r0 + k < r1) ? col[(size_t)(r0 + k) * stride4] : make_float4(0.f, 0.f, 0.f, 0.f);
+                acc4.x += ((v[0].x + v[1].x) + (v[2].x + v[3].x)) + ((v[4].x + v[5].x) + (v[6].x + v[7].x));
+                acc4.y += ((v[0].y + v[1].y) + (v[2].y + v[3].y)) + ((v[4].y + v[5].y) + (v[6].y + v[7].y));
+                acc4.z += ((v[0].z + v[1].z) + (v[2].z + v[3].z)) + ((v[4].z + v[5].z) + (v[6].z + v[7].z));
+                acc4.w += ((v[0].w + v[1].w) + (v[2].w + v[3].w)) + ((v[4].w + v[5].w) + (v[6].w + v[7].w));
+            }
+        }
+        s_q[part][2 * pp] = make_float2(acc4.x, acc4.y);
+        s_q[part][2 * pp + 1] = make_float2(acc4.z, acc4.w);
+    }
+    __syncthreads();
+    // the arithmetic of sfm_sym_epilogue_kernel without border / obstacle forces (pedestrian_simulation.py:57-83,
+    // forces.py:40-52): acceleration towards the waypoint, capped velocity, position, arrival -> next waypoint
+    auto finish = [&](const float2 g) {
+        const float fpx = a.en_ped ? a.ped.negA * g.x : 0.f, fpy = a.en_ped ? a.ped.negA * g.y : 0.f;
+        const float x = st.x, y = st.y, vx = st.z, vy = st.w, ts = o.z;
+        float wx = o.x, wy = o.y;
+        float fax = 0.f, fay = 0.f;
+        if (a.en_acc) {
+            const float tx_ = wx - x, ty_ = wy - y;
+            const float nrm = sqrtf(fmaf(tx_, tx_, ty_ * ty_));
+            const float inv = (nrm == 0.0f) ? 1.0f : 1.0f / nrm;
+            fax = (ts * (tx_ * inv) - vx) * a.inv_tau;
+            fay = (ts * (ty_ * inv) - vy) * a.inv_tau;
+        }
+        const float Fx = fax + fpx, Fy = fay + fpy;
+        float nvx = fmaf(a.dt, Fx, vx), nvy = fmaf(a.dt, Fy, vy);
+        float sp = sqrtf(fmaf(nvx, nvx, nvy * nvy));
+        sp = (sp == 0.0f) ? 1.0f : sp;
+        const float fac = fminf(1.0f, (ts * a.max_speed_factor) / sp);
+        nvx *= fac; nvy *= fac;
+        float nx = x, ny = y;
+        if (a.flags & 1u) { nx = fmaf(a.dt, nvx, x); ny = fmaf(a.dt, nvy, y); }
+        const float4 ns = make_float4(nx, ny, nvx, nvy);
+        if (diag_item) {                                             // this workgroup stores the group
+            if (a.flags & 2u) {
+                const float ax_ = wx - x, ay_ = wy - y;
+                if (fmaf(ax_, ax_, ay_ * ay_) < a.arrive_thr2) {
+                    const uint32_t nd = nd0 + 1u;
+                    wx = waypoint_coord(a.seed, pid, nd, 0u, a.world_side);
+                    wy = waypoint_coord(a.seed, pid, nd, 1u, a.world_side);
+                    a.draws[i] = nd;
+                }
+            }
+            f.own_next[i] = make_float4(wx, wy, o.z, o.w);
+            a.pk_next[i] = ns;
+        }
+        s_st[p] = ns;
+    };
+    bool bad = false;
+    if (lower && present) {
+        if (integrate && live) {
+            float2 g = s_q[0][p];
+#pragma unroll
+            for (int k = 1; k < PARTS; ++k) { const float2 q = s_q[k][p]; g.x += q.x; g.y += q.y; }
+            bad = a.en_ped && (!(fabsf(g.x) < __builtin_inff()) || !(fabsf(g.y) < __builtin_inff()));
+            if (bad) s_any = 1; else finish(g);
+        } else {
+            s_st[p] = st;                                            // ghosts, and the first launch of a run: as stored
+        }
+    }
+    if (lower) s_badrow[p] = bad ? 1 : 0;
+    __syncthreads();
+    if (s_any) {
+        // coincident pairs: the rows that caught a NaN are recomputed with the exact ordered body (rare; every workgroup that
+        // holds such a row does it, and they all get the same bits)
+        const int N = a.N;
+        for (int q = wave; q < 2 * GROUP; q += NW) {
+            if (!s_badrow[q]) continue;                                  // uniform
+            const int Gq = (q < GROUP) ? GX : GY;
+            const int ip = Gq * GROUP + (q & (GROUP - 1));
+            const float4 si = a.pk_cur[ip];
+            const float xi = uniform(si.x), yi = uniform(si.y), vxi = uniform(si.z), vyi = uniform(si.w);
+            float gx = 0.f, gy = 0.f;
+            for (int j0 = 0; j0 < N; j0 += WAVE) {
+                const int j = j0 + lane;
+                const float4 pj = a.pk_cur[min(j, N - 1)];
+                float cx = 0.f, cy = 0.f, cz = 0.f, rinv;
+                moussaid<false, RAD, true>(a.ped, pj.x - xi, pj.y - yi, 0.f, vxi - pj.z, vyi - pj.w, 0.f,
+                                           RAD ? a.radius[ip] + a.radius[min(j, N - 1)] : 0.f, cx, cy, cz, rinv);
+                const bool valid = (j < N) & (j != ip);
+                gx += valid ? cx : 0.f;
+                gy += valid ? cy : 0.f;
+            }
+            gx = wave_sum(gx);
+            gy = wave_sum(gy);
+            if (lane == 0) s_part[q] = make_float2(gx, gy);
+        }
+        __syncthreads();
+        if (bad) finish(s_part[p]);
+        __syncthreads();
+    }
+
+    // ---- 2. this workgroup's tile pairs on the new state: every wave SPW systolic steps (sfm_pair_sym_kernel's step)
+    int ia, ib, sig0;                             // LDS slots of the travelling / resident tile's lane 0, first rotation
+    bool diag = false, work = true;
+    if (diag_item) {
+        const int sel = wave / (NW / 2);          // lower half of the waves: group GX, upper half: group GY
+        const int lw = wave % (NW / 2);
+        const int base = sel * GROUP;
+        const int Gd = sel ? GY : GX;
+        if (lw < 2 * D) {                         // the two diagonal tiles: sigma 1..32, D waves each
+            const int tl = lw / D;
+            ia = ib = base + tl * WAVE;
+            sig0 = 1 + (lw % D) * SPW;
+            diag = true;
+            work = Gd < n_g && 2 * Gd + tl < n_t;
+        } else {                                  // tile 0 travelling past tile 1: sigma 0..63
+            ia = base; ib = base + WAVE;
+            sig0 = (lw - 2 * D) * SPW;
+            work = Gd < n_g && 2 * Gd + 1 < n_t;
+        }
+    } else {
+        const int q = wave / (NW / 4);            // (tile of GX, tile of GY): 00 01 10 11
+        ia = (q >> 1) * WAVE;
+        ib = GROUP + (q & 1) * WAVE;
+        sig0 = (wave % (NW / 4)) * SPW;
+        work = 2 * GX + (q >> 1) < n_t && 2 * GY + (q & 1) < n_t;
+    }
+    float fxi = 0.f, fyi = 0.f, fxj = 0.f, fyj = 0.f;
+    int i_end_loc = lane;
+    if (work) {
+        const float4 pj = s_st[ib + lane];
+        const int i_loc0 = (lane + f.dir * sig0) & (WAVE - 1);
+        const float4 pi0 = s_st[ia + i_loc0];
+        float rj = 0.f, ri = 0.f;
+        if (RAD) { rj = s_rad[ib + lane]; ri = s_rad[ia + i_loc0]; }
+        const IxConst& c = a.ped;
+        float xi = pi0.x, yi = pi0.y, uxi = c.lam * pi0.z, uyi = c.lam * pi0.w;
+        const float ujx = c.lam * pj.z, ujy = c.lam * pj.w;
+        auto step = [&](bool both) {
+            const float dx = pj.x - xi, dy = pj.y - yi;
+            const float d2 = fmaf(dx, dx, dy * dy);
+            float cx, cy;
+            moussaid_planar<RAD, false>(c, dx, dy, d2, uxi - ujx, uyi - ujy, RAD ? ri + rj : 0.f, cx, cy);
+            fxi += cx;
+            fyi += cy;
+            if (both) { fxj -= cx; fyj -= cy; }
+            xi = rot1(xi); yi = rot1(yi); uxi = rot1(uxi); uyi = rot1(uyi);
+            if (RAD) ri = rot1(ri);
+            fxi = rot1(fxi); fyi = rot1(fyi);
+        };
+        // sigma = 32 on a diagonal tile meets every unordered pair {l, l+32} in BOTH lanes: one-sided there
+        const bool tail_one_sided = diag && (sig0 + SPW - 1 == 32);  // uniform
+#pragma unroll 1
+        for (int s = 0; s < SPW - 1; ++s) step(true);
+        if (tail_one_sided) step(false); else step(true);
+        i_end_loc = (lane + f.dir * (sig0 + SPW)) & (WAVE - 1);
+    }
+    s_fi[wave][i_end_loc] = make_float2(fxi, fyi);
+    s_fj[wave][lane] = make_float2(fxj, fyj);
+    __syncthreads();
+    if (!lower || !present) return;
+    const int tl = (p >> 6) & 1, l = lane;       // tile of the group, pedestrian of the tile
+    float2 r = make_float2(0.f, 0.f);
+    int row;                                     // partner group = slab row
+    if (diag_item) {
+        const int w0 = (p < GROUP) ? 0 : NW / 2;
+#pragma unroll
+        for (int k = 0; k < D; ++k) {            // the tile's own diagonal item: both sides are this tile
+            const float2 u = s_fi[w0 + tl * D + k][l], v = s_fj[w0 + tl * D + k][l];
+            r.x += u.x + v.x; r.y += u.y + v.y;
+        }
+#pragma unroll
+        for (int k = 0; k < 2 * D; ++k) {        // the other tile of the group
+            const float2 u = tl ? s_fj[w0 + 2 * D + k][l] : s_fi[w0 + 2 * D + k][l];
+            r.x += u.x; r.y += u.y;
+        }
+        row = G;
+    } else if (p < GROUP) {                      // force on GX's pedestrians from GY: the travelling sides
+#pragma unroll
+        for (int k = 0; k < NW / 2; ++k) { const float2 u = s_fi[tl * (NW / 2) + k][l]; r.x += u.x; r.y += u.y; }
+        row = GY;
+    } else {                                     // force on GY's pedestrians from GX: the resident sides
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int k = 0; k < NW / 4; ++k) { const float2 u = s_fj[(2 * h + tl) * (NW / 4) + k][l]; r.x += u.x; r.y += u.y; }
+        row = GX;
+    }
+    f.slab_next[(size_t)row * a.N_pad + i] = r;
+}
+
 // Dynamic obstacles on the device (obstacles.py:297-329 without the simulator): one wave per vehicle moves the centre
 // by dt*v (advance != 0) and regenerates its ring p = c + R(yaw) u, the lanes over the ring points.
 __global__ __launch_bounds__(BLOCK) void sfm_dynamic_boxes_kernel(float4* __restrict__ ctr, const int* __restrict__ off,
@@ -1868,6 +2168,22 @@ hipError_t launch_sym_epilogue(bool rad, const TickArgs& a, const SymArgs& sa, h
     const bool thin = sa.n_t >= 1024 && !sa.cost;
     if (rad) { if (thin) launch_sym_epilogue_t<true, 4>(a, sa, st); else launch_sym_epilogue_t<true, EPI_WAVES>(a, sa, st); }
     else { if (thin) launch_sym_epilogue_t<false, 4>(a, sa, st); else launch_sym_epilogue_t<false, EPI_WAVES>(a, sa, st); }
+    return hipGetLastError();
+}
+
+// one launch of the fused tick (FusedArgs::mode)
+hipError_t launch_fused_tick(bool rad, const TickArgs& a, const FusedArgs& f, hipStream_t st) {
+    if (a.N <= 1 || f.n_g < 2) return hipErrorInvalidValue;
+    const int n_g = f.n_g, diag = (n_g + 1) / 2;            // diagonal items, full shifts, the half shift of an even n_g
+    const dim3 grid(diag + n_g * ((n_g - 1) / 2) + ((n_g & 1) ? 0 : n_g / 2));
+    static const int nw = getenv("SFM_FUSED_WAVES") ? atoi(getenv("SFM_FUSED_WAVES")) : 16;      // A/B only
+    if (nw == 8) {
+        if (rad) hipLaunchKernelGGL((sfm_fused_tick_kernel<true, 8>), grid, dim3(8 * WAVE), 0, st, a, f);
+        else hipLaunchKernelGGL((sfm_fused_tick_kernel<false, 8>), grid, dim3(8 * WAVE), 0, st, a, f);
+    } else {
+        if (rad) hipLaunchKernelGGL((sfm_fused_tick_kernel<true, 16>), grid, dim3(16 * WAVE), 0, st, a, f);
+        else hipLaunchKernelGGL((sfm_fused_tick_kernel<false, 16>), grid, dim3(16 * WAVE), 0, st, a, f);
+    }
     return hipGetLastError();
 }
 

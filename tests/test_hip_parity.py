@@ -676,6 +676,98 @@ def test_dealt_item_order_changes_nothing_but_time(monkeypatch):
         assert np.allclose(a, b, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("n,use_radius,coincide", [(256, False, False), (300, True, False), (1000, False, True), (2048, False, False), (4096, False, False),
+                                                   (4160, True, False), (8000, False, False)])
+def test_fused_tick_matches_the_two_kernel_tick(n, use_radius, coincide, monkeypatch):
+    """sfm_run on a whole planar crowd with the acceleration and pedestrian forces only takes the fused tick (one launch per
+    tick: the epilogue of tick t is the prologue of tick t+1's pair kernel).  It sums the same terms in another
+    order than the two-kernel tick, so after 12 device-resident ticks with waypoint redraws the two agree to rounding, draw
+    counters included -- for whole tiles, ragged tiles, odd tile and group counts, use_ped_radius, and with a coincident pair
+    (different velocities: finite in the reference, a NaN in the fast body that both paths must catch and recompute).
+    Two runs of the fused tick are bit-identical."""
+    # (use_ped_radius at 1 ped/m2 would have radii overlap: huge forces and a chaotic crowd that magnifies rounding a millionfold in 12 ticks)
+    sc = scenarios.make_scenario(n, 4321 + n, density=0.25 if use_radius else 1.0)
+    if coincide:
+        sc.loc[n // 2] = sc.loc[n // 2 + 70]                  # two pedestrians of different tiles at the same place
+        sc.loc[5] = sc.loc[6]                                 # ... and two of the same tile
+    cfg = default_sfm_config(("acceleration_force", "pedestrian_force"))
+    cfg["use_ped_radius"] = use_radius
+    out = {}
+    for tag, fused in (("fused", "1"), ("again", "1"), ("two-kernel", "0")):
+        monkeypatch.setenv("SFM_FUSED", fused)
+        eng = SfmEngine(cfg, 0.05)
+        try:
+            eng.upload_state(sc.loc, sc.vel, sc.waypoint, sc.target_speed, sc.radius, None)
+            eng.set_waypoint_stream(sc.seed, 0.2 * sc.world_side, 2.0)      # a small waypoint square: many arrivals in 12 ticks
+            eng.run(12, redraw=True)
+            assert ("fused" in eng.kernel_variant()) == (fused == "1"), eng.kernel_variant()
+            out[tag] = eng.state() + (eng.draw_counts(),)
+            eng.tick(record=True)                            # a single tick after a fused run finds state and waypoints where it expects them
+            out[tag] += (eng.velocities(),)
+        finally:
+            eng.close()
+    for a, b in zip(out["fused"], out["again"]):
+        assert np.array_equal(a, b, equal_nan=True)
+    loc, vel, wp, draws, v1 = out["fused"]
+    loc0, vel0, wp0, draws0, v10 = out["two-kernel"]
+    assert np.isfinite(loc).all() and np.isfinite(vel).all()
+    assert draws.sum() > 0, "no arrival in the run: the redraw branch was not exercised"
+    # (rounding differences grow along a trajectory -- a close encounter amplifies them -- so this is a bound on drift, not the
+    #  parity tolerance; a missing or doubled tile pair shows as 1e-2 and more)
+    dev = max(np.abs(loc - loc0).max(), np.abs(vel - vel0).max(), np.abs(v1 - v10).max())
+    print(f"fused vs two-kernel tick, N={n}: max deviation after 12 ticks {dev:.3g}")
+    assert dev < 2e-4, dev
+    same = (draws == draws0)
+    assert same.mean() > 0.999                               # (an arrival within rounding of the 2 m threshold may fall a tick apart)
+    assert np.array_equal(wp[same], wp0[same])
+
+
+def test_fused_runs_carry_on_only_when_nothing_came_between(monkeypatch):
+    """A fused run leaves the partial forces of its final state behind, and the next sfm_run / sfm_tick on the handle starts from
+    them -- one launch per tick, no launch in front -- but only if it is the very next call.  Whatever comes between (a download,
+    new parameters, a new state) the results must be those of the plain sequence: split runs, runs with a download in between and
+    single ticks after a run are bit-identical to one long run; with new parameters in between they follow the two-kernel tick."""
+    n = 2500
+    sc = scenarios.make_scenario(n, 777, density=1.0)
+    cfg = default_sfm_config(("acceleration_force", "pedestrian_force"))
+    cfg2 = default_sfm_config(("acceleration_force", "pedestrian_force"))
+    cfg2["pedestrian_force"] = dict(cfg2["pedestrian_force"], A=2.0 * cfg2["pedestrian_force"]["A"])
+
+    def fresh(fused="1"):
+        monkeypatch.setenv("SFM_FUSED", fused)
+        e = SfmEngine(cfg, 0.05)
+        e.upload_state(sc.loc, sc.vel, sc.waypoint, sc.target_speed, sc.radius, None)
+        e.set_waypoint_stream(sc.seed, 0.2 * sc.world_side, 2.0)
+        return e
+
+    def end(e):
+        out = e.state() + (e.draw_counts(),)
+        e.close()
+        return out
+
+    e = fresh(); e.run(12, redraw=True); assert e.timing()[2] == 13; one = end(e)
+    e = fresh(); e.run(5, redraw=True); e.run(7, redraw=True); assert e.timing()[2] == 7; split = end(e)
+    e = fresh(); e.run(5, redraw=True); e.state(); e.run(7, redraw=True); assert e.timing()[2] == 8; looked = end(e)
+    e = fresh(); e.run(5, redraw=True)
+    for _ in range(7):
+        e.tick(integrate=True, redraw=True)
+        assert "fused" in e.kernel_variant()
+    single = end(e)
+    for other in (split, looked, single):
+        for a, b in zip(one, other):
+            assert np.array_equal(a, b)
+    # new parameters between two runs: the carried partial forces were computed with the old ones and must not be used
+    res = {}
+    for fused in ("1", "0"):
+        e = fresh(fused); e.run(5, redraw=True); e.set_params(cfg2, 0.05); e.run(7, redraw=True); res[fused] = end(e)
+        e = fresh(fused); e.run(5, redraw=True)
+        e.upload_state(sc.loc, sc.vel, sc.waypoint, sc.target_speed, sc.radius, None); e.run(7, redraw=True); res[fused + "u"] = end(e)
+    assert np.abs(res["1"][1] - one[1]).max() > 1e-3                     # the stronger repulsion shows
+    for k in ("1", "1u"):
+        for a, b in zip(res[k][:2], res["0" if k == "1" else "0u"][:2]):
+            assert np.abs(a - b).max() < 2e-4
+
+
 def _arc(center, radius, a0, a1, spacing=0.1):
     n = max(8, int(abs(a1 - a0) * radius / spacing))
     th = np.linspace(a0, a1, n)
