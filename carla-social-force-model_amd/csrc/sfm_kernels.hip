@@ -1471,12 +1471,17 @@ __global__ __launch_bounds__(1024) void sfm_schedule_kernel(const int* __restric
 // order) and wave 0 integrates the 64 pedestrians lane-parallel with coalesced loads and stores (geometry
 // forces come from sfm_geometry_kernel).  Latency-bound by design: few, short chains.
 constexpr int EPI_WAVES = 16;
+#ifndef EPI_INFLIGHT
+#define EPI_INFLIGHT 8                     // slab-row loads a wave keeps in flight under a cutoff (a multiple of 4; the sum's association follows it)
+#endif
 
 template <bool RAD, int EW>
 __global__ __launch_bounds__(EW * WAVE) void sfm_sym_epilogue_kernel(const TickArgs a, const SymArgs sa) {
     __shared__ float2 s_sum[EW][WAVE];
     __shared__ float2 s_exact[WAVE];
     __shared__ int s_bad[EW];
+    __shared__ uint16_t s_own[EW][4096 / EW];   // two-level cutoff: the strips a wave sums (n_strips <= n_t <= 4096 under a cutoff)
+    __shared__ uint16_t s_kept[EW][4 * WAVE];   // ... and the kept tiles of four of them
     const int tid = threadIdx.x;
     const int lane = tid & (WAVE - 1);
     const int wave = uniform(tid >> 6);
@@ -1509,60 +1514,103 @@ __global__ __launch_bounds__(EW * WAVE) void sfm_sym_epilogue_kernel(const TickA
     // 1. slab column sums
     float2 acc = make_float2(0.f, 0.f);
     if (a.en_ped && a.tile_box && sa.n_strips > 0) {
-        // cutoff on, large crowd: wave w owns strips w, w+16, ... (sfm_pair_list2_kernel's two levels: a negligible strip
-        // holds only negligible tiles); its lanes test the tiles of a surviving strip and only the rows of evaluated tile
-        // pairs are read (fixed order, deterministic)
+        // cutoff on, large crowd (sfm_pair_list2_kernel's two levels: a negligible strip holds only negligible tiles).  Three
+        // passes, each with all of its loads in flight together instead of a round trip per strip (this kernel is a latency
+        // chain: 58 -> 36 us at c5): (1) lanes over the strips -- the survivors are dealt round-robin to the waves; (2) the tiles
+        // of four own strips at a time, lanes over tiles -- the kept ones go to a list in LDS; (3) their slab rows, EPI_INFLIGHT
+        // at a time.  Only the rows of evaluated tile pairs are read, in a fixed order (deterministic).
         const float2* col = sa.slab + i;
         const float4 bt = a.tile_box[t];
         const float vt = a.tile_vmax[t];
-        for (int s = wave; s < sa.n_strips; s += EW) {
-            if (tiles_negligible(bt, vt, sa.sbox[s], sa.svmax[s], a.ped.lam, a.cut_scale, a.cut_pad)) continue;   // uniform
-            for (int q0 = 0; q0 < sa.tps; q0 += WAVE) {
-                const int u0 = s * sa.tps + q0, u = u0 + lane;
-                bool keep = false;
-                if (q0 + lane < sa.tps && u < sa.n_t)
-                    keep = !tiles_negligible(bt, vt, a.tile_box[u], a.tile_vmax[u], a.ped.lam, a.cut_scale, a.cut_pad);
-                unsigned long long m = __ballot(keep);
-                while (m) {                               // up to four independent row loads in flight
-                    float2 v[4];
+        uint16_t* own = s_own[wave];
+        uint16_t* kept = s_kept[wave];
+        int n_alive = 0;
+        for (int s0 = 0; s0 < sa.n_strips; s0 += WAVE) {
+            const int s = s0 + lane;
+            const int sc = min(s, sa.n_strips - 1);
+            const bool alive = s < sa.n_strips && !tiles_negligible(bt, vt, sa.sbox[sc], sa.svmax[sc], a.ped.lam, a.cut_scale, a.cut_pad);
+            const unsigned long long ms = __ballot(alive);
+            const int rank = n_alive + __popcll(ms & ((1ull << lane) - 1ull));
+            if (alive && (rank % EW) == wave) own[rank / EW] = (uint16_t)s;
+            n_alive += __popcll(ms);
+        }
+        const int n_own = n_alive > wave ? (n_alive - wave - 1) / EW + 1 : 0;   // survivors of rank wave, wave + EW, ...
+        const int cps = (sa.tps + WAVE - 1) / WAVE;                             // 64-tile chunks per strip
+        const int n_units = n_own * cps;
+        for (int k = 0; k < n_units; k += 4) {
+            float4 tb[4];
+            float tv[4];
+            int uu[4];
+            bool ok[4];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        v[q] = make_float2(0.f, 0.f);
-                        if (m) {
-                            const int b = __ffsll((long long)m) - 1;
-                            m &= m - 1;
-                            v[q] = col[(size_t)(u0 + b) * sa.stride];
-                        }
-                    }
-                    acc.x += (v[0].x + v[1].x) + (v[2].x + v[3].x);
-                    acc.y += (v[0].y + v[1].y) + (v[2].y + v[3].y);
+            for (int j = 0; j < 4; ++j) {
+                const int e = min(k + j, n_units - 1);
+                const int q0 = (e % cps) * WAVE;
+                const int u = own[e / cps] * sa.tps + q0 + lane;
+                ok[j] = k + j < n_units && q0 + lane < sa.tps && u < sa.n_t;
+                uu[j] = ok[j] ? u : t;
+                tb[j] = a.tile_box[uu[j]];
+                tv[j] = a.tile_vmax[uu[j]];
+            }
+            int n_kept = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool keep = ok[j] && !tiles_negligible(bt, vt, tb[j], tv[j], a.ped.lam, a.cut_scale, a.cut_pad);
+                const unsigned long long m = __ballot(keep);
+                if (keep) kept[n_kept + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)uu[j];
+                n_kept += __popcll(m);
+            }
+            for (int r = 0; r < n_kept; r += EPI_INFLIGHT) {
+                float2 v[EPI_INFLIGHT];
+#pragma unroll
+                for (int q = 0; q < EPI_INFLIGHT; ++q)
+                    v[q] = (r + q < n_kept) ? col[(size_t)kept[r + q] * sa.stride] : make_float2(0.f, 0.f);
+#pragma unroll
+                for (int q = 0; q < EPI_INFLIGHT; q += 4) {
+                    acc.x += (v[q].x + v[q + 1].x) + (v[q + 2].x + v[q + 3].x);
+                    acc.y += (v[q].y + v[q + 1].y) + (v[q + 2].y + v[q + 3].y);
                 }
             }
         }
     } else if (a.en_ped && a.tile_box) {
-        // cutoff on: wave w owns partner tiles w, w+16, ...; its lanes test 64 of them at a time and only the rows of
-        // evaluated tile pairs are read (ascending order, deterministic)
+        // cutoff on, flat: wave w owns partner tiles w, w + EW, ...; its lanes test 64 of them at a time, four such chunks with
+        // their boxes in flight together, the kept tiles go to a list in LDS and their rows are read EPI_INFLIGHT at a time
+        // (only the rows of evaluated tile pairs, ascending order within a chunk: deterministic)
         const float2* col = sa.slab + i;
         const float4 bt = a.tile_box[t];
         const float vt = a.tile_vmax[t];
-        for (int base = wave; base < sa.n_t; base += EW * WAVE) {
-            const int u = base + EW * lane;
-            bool keep = false;
-            if (u < sa.n_t) keep = !tiles_negligible(bt, vt, a.tile_box[u], a.tile_vmax[u], a.ped.lam, a.cut_scale, a.cut_pad);
-            unsigned long long m = __ballot(keep);
-            while (m) {                                   // up to four independent row loads in flight
-                float2 v[4];
+        uint16_t* kept = s_kept[wave];
+        for (int base = wave; base < sa.n_t; base += 4 * EW * WAVE) {
+            float4 tb[4];
+            float tv[4];
+            int uu[4];
+            bool ok[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    v[q] = make_float2(0.f, 0.f);
-                    if (m) {
-                        const int b = __ffsll((long long)m) - 1;
-                        m &= m - 1;
-                        v[q] = col[(size_t)(base + EW * b) * sa.stride];
-                    }
+            for (int j = 0; j < 4; ++j) {
+                const int u = base + j * EW * WAVE + EW * lane;
+                ok[j] = u < sa.n_t;
+                uu[j] = ok[j] ? u : t;
+                tb[j] = a.tile_box[uu[j]];
+                tv[j] = a.tile_vmax[uu[j]];
+            }
+            int n_kept = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool keep = ok[j] && !tiles_negligible(bt, vt, tb[j], tv[j], a.ped.lam, a.cut_scale, a.cut_pad);
+                const unsigned long long m = __ballot(keep);
+                if (keep) kept[n_kept + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)uu[j];
+                n_kept += __popcll(m);
+            }
+            for (int r = 0; r < n_kept; r += EPI_INFLIGHT) {
+                float2 v[EPI_INFLIGHT];
+#pragma unroll
+                for (int q = 0; q < EPI_INFLIGHT; ++q)
+                    v[q] = (r + q < n_kept) ? col[(size_t)kept[r + q] * sa.stride] : make_float2(0.f, 0.f);
+#pragma unroll
+                for (int q = 0; q < EPI_INFLIGHT; q += 4) {
+                    acc.x += (v[q].x + v[q + 1].x) + (v[q + 2].x + v[q + 3].x);
+                    acc.y += (v[q].y + v[q + 1].y) + (v[q + 2].y + v[q + 3].y);
                 }
-                acc.x += (v[0].x + v[1].x) + (v[2].x + v[3].x);
-                acc.y += (v[0].y + v[1].y) + (v[2].y + v[3].y);
             }
         }
     } else if (a.en_ped) {                                   // wave w takes partner tiles w, w+16, ...
