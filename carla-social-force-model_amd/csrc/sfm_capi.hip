@@ -150,6 +150,7 @@ struct SfmHandle {
     size_t fslab_cap = 0;
     float4* own_alt = nullptr;             // the waypoints ping-pong with the state
     int own_alt_cap = 0;
+    int list_merge_mode = -1;              // SFM_LIST_MERGE=0: the flat tile-pair list always gets a launch of its own (A/B, tests)
     int fused_mode = -1;                   // SFM_FUSED=0: always the two-kernel tick (A/B, tests)
     bool used_fused = false;
     // A fused run ends with the partial forces of its final state already in fslab: the next sfm_run / sfm_tick carries on from
@@ -316,6 +317,8 @@ int sfm_create(const SfmParams* params, int device_id, SfmHandle** out) {
     if (ov) h->split_mode = atoi(ov);
     ov = getenv("SFM_GEO_AHEAD");
     if (ov) h->geo_ahead_mode = atoi(ov);
+    ov = getenv("SFM_LIST_MERGE");
+    if (ov) h->list_merge_mode = atoi(ov);
     ov = getenv("SFM_FUSED");
     if (ov) h->fused_mode = atoi(ov);
     ov = getenv("SFM_SCHED");
@@ -1189,6 +1192,7 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags, int phase = PHASE_
         static const int fork_ov = getenv("SFM_FORK") ? atoi(getenv("SFM_FORK")) : -1;      // A/B only: 0 / 1 = in line / side stream with carried boxes
         const bool fork_carried = fork_ov >= 0 ? fork_ov == 1 : h->n_t >= 1024;
         const bool fork = a.geo && n_local > 0 && sym && ((h->overlap_geo && (!(a.tile_box_out && !lite) || fork_carried)) || finishing);
+        bool list_in_geo = false;
         if (ahead) {
         } else if (fork) {
             HIP_TRY(h, hipEventRecord(h->ev_fork, h->stream));
@@ -1197,6 +1201,11 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags, int phase = PHASE_
             HIP_TRY(h, hipEventRecord(h->ev_join, h->aux));
             ++launches;
         } else if (a.geo && n_local > 0) {
+            // whole crowd, flat list, boxes and a zeroed counter carried over from the previous epilogue: the list is built by extra
+            // workgroups of this launch instead of a launch of its own between the geometry and the pair kernel (c3: 4 -> 3 launches)
+            list_in_geo = sym && whole && carried && h->count_zeroed && list_cut && n_strips == 0 && !finishing && a.en_ped &&
+                          h->N > 1 && h->list_merge_mode != 0;
+            if (list_in_geo) { a.list_work = h->work; a.list_count = h->work_count; a.list_n_t = h->n_t; }
             HIP_TRY(h, launch_geometry(h->rad, a, h->stream));
             ++launches;
         }
@@ -1217,7 +1226,7 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags, int phase = PHASE_
             // a shard's epilogue leaves the list counter(s) at zero as well (its boxes cannot be carried -- the other ranks' rows
             // arrive in between -- but the memset can go)
             const bool shard_zero = !whole && list_cut && !sa.cost && (flags & SFM_TICK_INTEGRATE) && h->carry_mode != 0;
-            if (sa.work && !sa.cost) {
+            if (sa.work && !sa.cost && !list_in_geo) {
                 HIP_TRY(h, launch_sym_list(a, sa, h->stream, finishing ? LIST_REMOTE : LIST_ALL, (carried || !whole) && h->count_zeroed));
                 ++launches;
             }

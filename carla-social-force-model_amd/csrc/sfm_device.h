@@ -106,6 +106,11 @@ struct TickArgs {
     float* tile_vmax_out;     // the NEXT tick's state here (saves the next tick's sfm_tile_bounds_kernel launch)
     int lite;                 // 1: the "lite" cutoff (no tile-pair list) is what tile_box stands for
     FsmArgs fsm;
+    // Flat tile-pair list of a whole crowd built by extra workgroups of the geometry launch (block index >= list_block0) instead of
+    // a launch of its own: the boxes were left by the previous epilogue, so nothing stands in front of it.  list_work == null: off.
+    uint32_t* list_work;
+    int* list_count;
+    int list_n_t, list_block0;
     unsigned long long* geo_stamps;   // diagnostic runs only (SFM_GEO_STAMPS): per geometry workgroup {start, after find, after scan, end} of s_memrealtime
 };
 

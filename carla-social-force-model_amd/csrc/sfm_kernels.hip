@@ -464,12 +464,73 @@ __device__ __forceinline__ int geo_find(const TickArgs& a, const GeoLane& me, co
 
 // GW waves per tile: 16 for up to 1023 tiles (two workgroups per CU: 64 VGPRs, 64 KB of LDS each); 8 from 1024 tiles on --
 // a workgroup's life is a chain of memory round trips, not work, so four thinner workgroups per CU beat two fat ones there.
+// Compacts the tile-pair items the symmetric kernel has to evaluate: one candidate per thread, (bx, shift) with
+// bx an own tile and tb = bx + shift (mod n_t).  Own-own pairs are kept once (shift <= n_t / 2, as in the kernel's 2-D
+// grid); a pair with a tile of another rank is kept by both ranks, each evaluating its own side only (bit 31).
+// Diagonal items (shift 0) are always kept and carry two diagonal tiles each.
+constexpr uint32_t WORK_ONE_SIDED = 0x80000000u;
+// `partners`: PARTNERS_ALL, or only the items whose two tiles are both own (PARTNERS_OWN: what a shard can evaluate before the
+// other ranks' rows have arrived), or only the others (PARTNERS_REMOTE).
+constexpr int PARTNERS_ALL [[maybe_unused]] = 0, PARTNERS_OWN = 1, PARTNERS_REMOTE = 2;
+// Returns whether candidate (bx, shift) is an item, and the item.
+__device__ __forceinline__ bool list_candidate(const float4* __restrict__ box, const float* __restrict__ vmax, int n_t, int t_lo, int t_hi,
+                                               float lam, float cut_scale, float cut_pad, int partners, int bx, int shift, uint32_t& item) {
+    if (bx >= t_hi) return false;
+    bool keep;
+    uint32_t one = 0u;
+    if (shift == 0) {
+        keep = (bx - t_lo) < ((t_hi - t_lo + 1) >> 1) && partners != PARTNERS_REMOTE;
+    } else {
+        int tb = bx + shift;
+        if (tb >= n_t) tb -= n_t;
+        const bool own = tb >= t_lo && tb < t_hi;
+        if ((partners == PARTNERS_OWN && !own) || (partners == PARTNERS_REMOTE && own)) return false;
+        if (own) keep = shift <= (n_t >> 1) && !(!(n_t & 1) && shift == (n_t >> 1) && bx >= (n_t >> 1));
+        else { keep = true; one = WORK_ONE_SIDED; }
+        if (keep) keep = !tiles_negligible(box[bx], vmax[bx], box[tb], vmax[tb], lam, cut_scale, cut_pad);
+    }
+    item = (uint32_t)bx | ((uint32_t)shift << 16) | one;
+    return keep;
+}
+
+// Appends the kept items of a whole workgroup to the list with ONE atomic: the counter is a single word, a device-scope atomic
+// on it takes ~11 ns whatever else goes on, and a wave-level append (what `work[atomicAdd(count, 1)]` compiles to) made those
+// atomics the flat list kernel's whole duration (c4: ~800 waves with an item, 10 us).  Every thread of the workgroup must call it.
+// s_n: [waves + 1] ints of LDS.
+__device__ __forceinline__ void list_emit(bool keep, uint32_t item, uint32_t* __restrict__ work, int* __restrict__ count, int* s_n) {
+    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6, waves = (blockDim.x + WAVE - 1) >> 6;
+    const unsigned long long m = __ballot(keep);
+    if (lane == 0) s_n[wave] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int total = 0;
+        for (int w = 0; w < waves; ++w) { const int n = s_n[w]; s_n[w] = total; total += n; }   // exclusive prefix
+        const int base = total > 0 ? atomicAdd(count, total) : 0;
+        for (int w = 0; w < waves; ++w) s_n[w] += base;
+    }
+    __syncthreads();
+    if (keep) work[s_n[wave] + __popcll(m & ((1ull << lane) - 1ull))] = item;
+}
+
 template <bool RAD, int GW>
 __global__ __launch_bounds__(GW * WAVE, 8) void sfm_geometry_kernel(const TickArgs a) {
     __shared__ float2 s_row[GW][WAVE];
     __shared__ float s_acc[GW][6][WAVE];
     __shared__ GeoItem s_item[GW][GEO_ITEMS];
     __shared__ int s_count[GW];
+    if (a.list_work && (int)blockIdx.x >= a.list_block0) {             // the extra workgroups: the next pair kernel's tile-pair list
+        if (blockIdx.y == 0) {
+            __shared__ int s_n[GW + 1];
+            const int idx = ((int)blockIdx.x - a.list_block0) * (GW * WAVE) + (int)threadIdx.x;     // shift-major, bx fastest
+            const int shift = idx / a.list_n_t;
+            uint32_t item = 0u;
+            const bool keep = shift <= (a.list_n_t >> 1) &&
+                              list_candidate(a.tile_box, a.tile_vmax, a.list_n_t, 0, a.list_n_t, a.ped.lam, a.cut_scale, a.cut_pad,
+                                             PARTNERS_ALL, idx - shift * a.list_n_t, shift, item);
+            list_emit(keep, item, a.list_work, a.list_count, s_n);
+        }
+        return;
+    }
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = uniform((int)(threadIdx.x >> 6));
     unsigned long long st0 = 0, st1 = 0, st2 = 0;
@@ -1100,34 +1161,14 @@ __global__ __launch_bounds__(TSB_WAVES * WAVE) void sfm_tile_strip_bounds_kernel
     }
 }
 
-// Compacts the tile-pair items the symmetric kernel has to evaluate: one candidate per thread, (bx, shift) with
-// bx an own tile and tb = bx + shift (mod n_t).  Own-own pairs are kept once (shift <= n_t / 2, as in the kernel's 2-D
-// grid); a pair with a tile of another rank is kept by both ranks, each evaluating its own side only (bit 31).
-// Diagonal items (shift 0) are always kept and carry two diagonal tiles each.
-constexpr uint32_t WORK_ONE_SIDED = 0x80000000u;
-// `partners`: PARTNERS_ALL, or only the items whose two tiles are both own (PARTNERS_OWN: what a shard can evaluate before the
-// other ranks' rows have arrived), or only the others (PARTNERS_REMOTE).
-constexpr int PARTNERS_ALL [[maybe_unused]] = 0, PARTNERS_OWN = 1, PARTNERS_REMOTE = 2;
-__global__ void sfm_pair_list_kernel(const float4* __restrict__ box, const float* __restrict__ vmax, int n_t, int t_lo, int t_hi,
-                                     float lam, float cut_scale, float cut_pad, uint32_t* __restrict__ work,
-                                     int* __restrict__ count, int partners) {
-    const int bx = t_lo + blockIdx.x * blockDim.x + threadIdx.x;
-    const int shift = blockIdx.y;
-    if (bx >= t_hi) return;
-    bool keep;
-    uint32_t one = 0u;
-    if (shift == 0) {
-        keep = (bx - t_lo) < ((t_hi - t_lo + 1) >> 1) && partners != PARTNERS_REMOTE;
-    } else {
-        int tb = bx + shift;
-        if (tb >= n_t) tb -= n_t;
-        const bool own = tb >= t_lo && tb < t_hi;
-        if ((partners == PARTNERS_OWN && !own) || (partners == PARTNERS_REMOTE && own)) return;
-        if (own) keep = shift <= (n_t >> 1) && !(!(n_t & 1) && shift == (n_t >> 1) && bx >= (n_t >> 1));
-        else { keep = true; one = WORK_ONE_SIDED; }
-        if (keep) keep = !tiles_negligible(box[bx], vmax[bx], box[tb], vmax[tb], lam, cut_scale, cut_pad);
-    }
-    if (keep) work[atomicAdd(count, 1)] = (uint32_t)bx | ((uint32_t)shift << 16) | one;
+__global__ __launch_bounds__(256) void sfm_pair_list_kernel(const float4* __restrict__ box, const float* __restrict__ vmax, int n_t, int t_lo,
+                                                            int t_hi, float lam, float cut_scale, float cut_pad,
+                                                            uint32_t* __restrict__ work, int* __restrict__ count, int partners) {
+    __shared__ int s_n[5];
+    uint32_t item = 0u;
+    const bool keep = list_candidate(box, vmax, n_t, t_lo, t_hi, lam, cut_scale, cut_pad, partners,
+                                     t_lo + (int)(blockIdx.x * blockDim.x + threadIdx.x), (int)blockIdx.y, item);
+    list_emit(keep, item, work, count, s_n);
 }
 
 // The same list for large crowds, two levels: one wave per own tile tests the strips first, 64 at a time (a strip's box
@@ -2121,12 +2162,19 @@ hipError_t launch_geometry(bool rad, const TickArgs& a, hipStream_t st) {
     const int grid = ((a.i_end + WAVE - 1) >> 6) - (a.i_begin >> 6);      // tiles overlapping the shard
     static const int gw_ov = getenv("SFM_GEO_WAVES") ? atoi(getenv("SFM_GEO_WAVES")) : 0;        // A/B only
     const bool thin = gw_ov ? gw_ov == 8 : grid >= 1024;
+    TickArgs b = a;
+    int extra = 0;                                  // workgroups that build the flat tile-pair list (TickArgs::list_work)
+    if (a.list_work) {
+        const int threads = thin ? 8 * WAVE : GEO_BLOCK;
+        extra = (a.list_n_t * (a.list_n_t / 2 + 1) + threads - 1) / threads;
+        b.list_block0 = grid;
+    }
     if (thin) {
-        if (rad) hipLaunchKernelGGL((sfm_geometry_kernel<true, 8>), dim3(grid, a.geo_slices), dim3(8 * WAVE), 0, st, a);
-        else hipLaunchKernelGGL((sfm_geometry_kernel<false, 8>), dim3(grid, a.geo_slices), dim3(8 * WAVE), 0, st, a);
+        if (rad) hipLaunchKernelGGL((sfm_geometry_kernel<true, 8>), dim3(grid + extra, a.geo_slices), dim3(8 * WAVE), 0, st, b);
+        else hipLaunchKernelGGL((sfm_geometry_kernel<false, 8>), dim3(grid + extra, a.geo_slices), dim3(8 * WAVE), 0, st, b);
     } else {
-        if (rad) hipLaunchKernelGGL((sfm_geometry_kernel<true, GEO_WAVES>), dim3(grid, a.geo_slices), dim3(GEO_BLOCK), 0, st, a);
-        else hipLaunchKernelGGL((sfm_geometry_kernel<false, GEO_WAVES>), dim3(grid, a.geo_slices), dim3(GEO_BLOCK), 0, st, a);
+        if (rad) hipLaunchKernelGGL((sfm_geometry_kernel<true, GEO_WAVES>), dim3(grid + extra, a.geo_slices), dim3(GEO_BLOCK), 0, st, b);
+        else hipLaunchKernelGGL((sfm_geometry_kernel<false, GEO_WAVES>), dim3(grid + extra, a.geo_slices), dim3(GEO_BLOCK), 0, st, b);
     }
     return hipGetLastError();
 }
@@ -2213,7 +2261,8 @@ static void launch_sym_epilogue_t(const TickArgs& a, const SymArgs& sa, hipStrea
 // mid-sized-crowd feature, needs the 16-wave form).
 hipError_t launch_sym_epilogue(bool rad, const TickArgs& a, const SymArgs& sa, hipStream_t st) {
     if (a.N <= 0) return hipSuccess;
-    const bool thin = sa.n_t >= 1024 && !sa.cost;
+    static const int ew_ov = getenv("SFM_EPI_WAVES") ? atoi(getenv("SFM_EPI_WAVES")) : 0;      // A/B only: 4 / 16
+    const bool thin = (ew_ov ? ew_ov == 4 : sa.n_t >= 1024) && !sa.cost;
     if (rad) { if (thin) launch_sym_epilogue_t<true, 4>(a, sa, st); else launch_sym_epilogue_t<true, EPI_WAVES>(a, sa, st); }
     else { if (thin) launch_sym_epilogue_t<false, 4>(a, sa, st); else launch_sym_epilogue_t<false, EPI_WAVES>(a, sa, st); }
     return hipGetLastError();
