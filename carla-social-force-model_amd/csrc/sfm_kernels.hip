@@ -1174,18 +1174,19 @@ __global__ __launch_bounds__(256) void sfm_pair_list_kernel(const float4* __rest
 // The same list for large crowds, two levels: one wave per own tile tests the strips first, 64 at a time (a strip's box
 // contains its tiles' boxes and its speed bounds theirs, and tiles_negligible is monotone in both, so a negligible strip
 // holds only negligible tiles -- the result is exactly the flat kernel's), then the tiles of the surviving strips.
-__global__ __launch_bounds__(BLOCK) void sfm_pair_list2_kernel(const float4* __restrict__ box, const float* __restrict__ vmax,
+constexpr int LIST2_WAVES = 16;          // tiles per workgroup = atomics saved
+__global__ __launch_bounds__(LIST2_WAVES * WAVE) void sfm_pair_list2_kernel(const float4* __restrict__ box, const float* __restrict__ vmax,
                                                                const SymArgs sa, float lam, uint32_t* __restrict__ work,
                                                                int* __restrict__ count, int partners) {
     constexpr int BUF = 256;                              // a wave collects its items in LDS: one atomic per flush
-    __shared__ uint32_t s_item[WAVES_PER_BLOCK][BUF];
+    __shared__ uint32_t s_item[LIST2_WAVES][BUF];
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = uniform((int)(threadIdx.x >> 6));
     // one wave per own tile.  The list's single counter is what this kernel waits for (one device-scope atomic costs ~11 ns on one
     // word: 4096 of them were 46 of the kernel's 54 us at c5), so a wave only appends on its own when its LDS buffer overflows;
-    // at the end the 4 waves of a workgroup reserve their space with ONE atomic.
-    __shared__ int s_n[WAVES_PER_BLOCK], s_base;
-    const int bx = sa.t_lo + blockIdx.x * WAVES_PER_BLOCK + wave;
+    // at the end the 16 waves of a workgroup reserve their space with ONE atomic.
+    __shared__ int s_n[LIST2_WAVES], s_base;
+    const int bx = sa.t_lo + blockIdx.x * LIST2_WAVES + wave;
     const bool live = bx < sa.t_hi;
     uint32_t* buf = s_item[wave];
     int n_buf = 0;                                         // uniform
@@ -1205,59 +1206,66 @@ __global__ __launch_bounds__(BLOCK) void sfm_pair_list2_kernel(const float4* __r
         const bool hit = s < sa.n_strips && !tiles_negligible(bt, vt, sa.sbox[min(s, sa.n_strips - 1)], sa.svmax[min(s, sa.n_strips - 1)],
                                                               lam, sa.cut_scale, sa.cut_pad);
         unsigned long long ms = __ballot(hit);
-        // the surviving strips, one trip of 64 tiles at a time; the next trip's boxes are loaded before this one is examined
-        int s0 = -1, q0 = 0;                                   // current trip: tiles s0 + q0 + lane
-        auto advance = [&](int& ns0, int& nq0) {              // -> the trip after (ns0, nq0); ns0 = -1: none left
-            if (ns0 >= 0 && nq0 + WAVE < sa.tps) { nq0 += WAVE; return; }
-            if (!ms) { ns0 = -1; return; }
-            ns0 = (sb + __ffsll((long long)ms) - 1) * sa.tps;
+        // the surviving strips in trips of 64 tiles, FOUR trips at a time with their boxes in flight together (one trip at a time,
+        // the next one prefetched, left a chain of ~20 dependent round trips per tile: 18 us at c5)
+        int s0 = -1, q0 = 0;                                   // generator state: trip = tiles s0 + q0 + lane; s0 = -1: none left
+        auto advance = [&]() {
+            if (s0 >= 0 && q0 + WAVE < sa.tps) { q0 += WAVE; return; }
+            if (!ms) { s0 = -1; return; }
+            s0 = (sb + __ffsll((long long)ms) - 1) * sa.tps;
             ms &= ms - 1;
-            nq0 = 0;
+            q0 = 0;
         };
-        auto fetch = [&](int fs0, int fq0, float4& fb, float& fv, bool& ok) {
-            const int tb = fs0 + fq0 + lane;
-            ok = fs0 >= 0 && (fq0 + lane) < sa.tps && tb < n_t;
-            if (ok) { fb = box[tb]; fv = vmax[tb]; }
-        };
-        advance(s0, q0);
-        float4 cb = make_float4(0.f, 0.f, 0.f, 0.f), nb = cb;
-        float cv = 0.f, nv = 0.f;
-        bool c_ok = false, n_ok = false;
-        fetch(s0, q0, cb, cv, c_ok);
-        while (s0 >= 0) {
-            int ns0 = s0, nq0 = q0;
-            advance(ns0, nq0);
-            fetch(ns0, nq0, nb, nv, n_ok);
-            const int tb = s0 + q0 + lane;
-            bool keep = c_ok;
-            uint32_t item = 0u;
-            if (keep) {
-                int shift = tb - bx;
-                if (shift < 0) shift += n_t;
-                if (shift == 0) {
-                    keep = (bx - sa.t_lo) < ((sa.t_hi - sa.t_lo + 1) >> 1) && partners != PARTNERS_REMOTE;
-                } else {
-                    const bool own = tb >= sa.t_lo && tb < sa.t_hi;
-                    if ((partners == PARTNERS_OWN && !own) || (partners == PARTNERS_REMOTE && own)) keep = false;
-                    else if (own) keep = shift <= (n_t >> 1) && !(!(n_t & 1) && shift == (n_t >> 1) && bx >= (n_t >> 1));
-                    if (keep) keep = !tiles_negligible(bt, vt, cb, cv, lam, sa.cut_scale, sa.cut_pad);
-                    item = own ? 0u : WORK_ONE_SIDED;
+        for (;;) {
+            int tb[4];
+            float4 fb[4];
+            float fv[4];
+            bool ok[4];
+            bool any = false;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                advance();
+                any = any || s0 >= 0;
+                tb[j] = s0 + q0 + lane;
+                ok[j] = s0 >= 0 && (q0 + lane) < sa.tps && tb[j] < n_t;
+                const int tc = ok[j] ? tb[j] : bx;
+                fb[j] = box[tc];
+                fv[j] = vmax[tc];
+            }
+            if (!any) break;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                bool keep = ok[j];
+                uint32_t item = 0u;
+                if (keep) {
+                    int shift = tb[j] - bx;
+                    if (shift < 0) shift += n_t;
+                    if (shift == 0) {
+                        keep = (bx - sa.t_lo) < ((sa.t_hi - sa.t_lo + 1) >> 1) && partners != PARTNERS_REMOTE;
+                    } else {
+                        const bool own = tb[j] >= sa.t_lo && tb[j] < sa.t_hi;
+                        if ((partners == PARTNERS_OWN && !own) || (partners == PARTNERS_REMOTE && own)) keep = false;
+                        else if (own) keep = shift <= (n_t >> 1) && !(!(n_t & 1) && shift == (n_t >> 1) && bx >= (n_t >> 1));
+                        if (keep) keep = !tiles_negligible(bt, vt, fb[j], fv[j], lam, sa.cut_scale, sa.cut_pad);
+                        item = own ? 0u : WORK_ONE_SIDED;
+                    }
+                    item |= (uint32_t)bx | ((uint32_t)shift << 16);
                 }
-                item |= (uint32_t)bx | ((uint32_t)shift << 16);
+                const unsigned long long mk = __ballot(keep);
+                if (mk) {
+                    if (n_buf + WAVE > BUF) flush();
+                    if (keep) buf[n_buf + __popcll(mk & ((1ull << lane) - 1ull))] = item;
+                    n_buf += __popcll(mk);
+                }
             }
-            const unsigned long long mk = __ballot(keep);
-            if (mk) {
-                if (n_buf + WAVE > BUF) flush();
-                if (keep) buf[n_buf + __popcll(mk & ((1ull << lane) - 1ull))] = item;
-                n_buf += __popcll(mk);
-            }
-            s0 = ns0; q0 = nq0; cb = nb; cv = nv; c_ok = n_ok;
+            if (s0 < 0) break;
         }
     }
     if (lane == 0) s_n[wave] = n_buf;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const int total = (s_n[0] + s_n[1]) + (s_n[2] + s_n[3]);
+        int total = 0;
+        for (int w = 0; w < LIST2_WAVES; ++w) total += s_n[w];
         s_base = total ? atomicAdd(count, total) : 0;
     }
     __syncthreads();
@@ -2187,7 +2195,7 @@ hipError_t launch_sym_list(const TickArgs& a, const SymArgs& sa, hipStream_t st,
     const bool whole = sa.t_lo == 0 && sa.t_hi == sa.n_t;      // a shard also looks at partners behind it
     // own partners only (PARTNERS_OWN): the strips' boxes need every tile's box, which a shard does not have yet -- flat kernel
     if (sa.n_strips > 0 && partners != PARTNERS_OWN)
-        hipLaunchKernelGGL(sfm_pair_list2_kernel, dim3((sa.t_hi - sa.t_lo + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), dim3(BLOCK), 0, st,
+        hipLaunchKernelGGL(sfm_pair_list2_kernel, dim3((sa.t_hi - sa.t_lo + LIST2_WAVES - 1) / LIST2_WAVES), dim3(LIST2_WAVES * WAVE), 0, st,
                            a.tile_box, a.tile_vmax, sa, a.ped.lam, const_cast<uint32_t*>(sa.work), const_cast<int*>(sa.work_count),
                            partners);
     else
