@@ -904,9 +904,10 @@ static void fill_args(SfmHandle* h, TickArgs& a, uint32_t flags) {
     a.geo = any_geo ? h->geo : nullptr;
     {   // a handful of tiles cannot fill 256 CUs: split each tile's polylines over up to 8 workgroups
         const int tiles = std::max(1, (h->i_end + WAVE - 1) / WAVE - h->i_begin / WAVE);
-        // (round 2: with the straight-border shortcut a tile's scan is short, and every slice repeats the start-up chain:
-        //  c1, one tile, 17.3 us per tick at 8 slices, 16.5 at 4, 16.2 at 2, 18.1 at 1)
-        a.geo_slices = tiles <= 4 ? 2 : tiles <= 64 ? 4 : tiles <= 128 ? 2 : 1;
+        // (round 2: with the straight-border shortcut a tile's scan is short, and every slice repeats the start-up chain; c1, one
+        //  tile, with the polylines of all kinds dealt evenly over the slices: 18.3 us per tick at 1 slice, 15.8 at 2, 14.3 at 3,
+        //  13.9 at 4, 14.4 at 6, 14.5 at 8)
+        a.geo_slices = tiles <= 64 ? 4 : tiles <= 128 ? 2 : 1;
         if (h->geo_slices_override > 0) a.geo_slices = h->geo_slices_override;
     }
     // device-side vehicles move on at the end of an integrating tick: extra workgroups of the tick's last kernel
