@@ -20,7 +20,7 @@ hipError_t launch_arrived(const float4* pk, const float4* own, int N, float thr2
 hipError_t launch_sym_list(const TickArgs& a, const SymArgs& sa, hipStream_t st, int partners = 0, bool count_is_zero = false);
 hipError_t launch_sym_pair(bool rad, const TickArgs& a, const SymArgs& sa, hipStream_t st);
 hipError_t launch_sym_epilogue(bool rad, const TickArgs& a, const SymArgs& sa, hipStream_t st);
-hipError_t launch_fused_tick(bool rad, const TickArgs& a, const FusedArgs& f, hipStream_t st);
+hipError_t launch_fused_tick(bool rad, const TickArgs& a, const FusedArgs& f, hipStream_t st, int waves);
 hipError_t launch_schedule(const int* cost, int n_t, uint32_t* work, int* count, hipStream_t st);
 int sym_item_count(int n_t);
 hipError_t launch_strip_bounds(const float4* box, const float* vmax, int n_t, int tps, int n_strips, float4* sbox, float* svmax,
@@ -92,10 +92,8 @@ struct SfmHandle {
 
     // symmetric pedestrian-force path (single shard, planar, no radius)
     float2* slab = nullptr;
-    int* tile_flag = nullptr;
     int n_t = 0;
     size_t slab_cap = 0;
-    int tile_cap = 0;
     int dpp_dir = 0;
     int sym_mode = -1;                     // SFM_SYM: 0 off, 1 on when eligible, -1 auto
     // tile-granular cutoff of provably negligible pedestrian pairs
@@ -105,7 +103,7 @@ struct SfmHandle {
     size_t up_stage_cap = 0;               // device twin, one kernel spreads it over the arrays
     char* up_block = nullptr;
     size_t up_block_cap = 0;
-    size_t box_cap = 0, strip_cap = 0, flag_cap = 0;
+    size_t box_cap = 0, strip_cap = 0;
     float4* strip_box = nullptr;           // [n_t]: boxes / speeds of runs of tiles (two-level list building, n_t >= 1024)
     float* strip_vmax = nullptr;
     int box_cur = 0;
@@ -152,6 +150,7 @@ struct SfmHandle {
     int own_alt_cap = 0;
     int list_merge_mode = -1;              // SFM_LIST_MERGE=0: the flat tile-pair list always gets a launch of its own (A/B, tests)
     int fused_mode = -1;                   // SFM_FUSED=0: always the two-kernel tick (A/B, tests)
+    int fused_waves = 16, fused_blocked = 1;   // SFM_FUSED_WAVES=8 / SFM_FUSED_BLOCKED=0: its A/B variants (tests)
     bool used_fused = false;
     // A fused run ends with the partial forces of its final state already in fslab: the next sfm_run / sfm_tick carries on from
     // there (one launch per tick, no start-up launch) provided NOTHING else was called on the handle in between -- api_seq counts
@@ -321,6 +320,10 @@ int sfm_create(const SfmParams* params, int device_id, SfmHandle** out) {
     if (ov) h->list_merge_mode = atoi(ov);
     ov = getenv("SFM_FUSED");
     if (ov) h->fused_mode = atoi(ov);
+    ov = getenv("SFM_FUSED_WAVES");
+    if (ov && atoi(ov) == 8) h->fused_waves = 8;
+    ov = getenv("SFM_FUSED_BLOCKED");
+    if (ov) h->fused_blocked = atoi(ov);
     ov = getenv("SFM_SCHED");
     if (ov) h->sched_mode = atoi(ov);
     ov = getenv("SFM_REORDER");
@@ -391,7 +394,6 @@ int sfm_destroy(SfmHandle* h) {
     if (h->slab) hipFree(h->slab);
     if (h->fslab) hipFree(h->fslab);
     if (h->own_alt) hipFree(h->own_alt);
-    if (h->tile_flag) hipFree(h->tile_flag);
     for (void* q : {(void*)h->f_mode, (void*)h->f_target, (void*)h->f_initial, (void*)h->f_crossing, (void*)h->f_margin,
                     (void*)h->f_next, (void*)h->f_off, (void*)h->f_cursor, (void*)h->f_xy, (void*)h->f_cross})
         if (q) hipFree(q);
@@ -749,8 +751,6 @@ int sfm_upload_state(SfmHandle* h, int N, const float* x, const float* y, const 
     const size_t need = (size_t)h->n_t * (size_t)slab_stride(h->n_t);
     if (!z3 && h->dpp_dir != 0 && h->sym_mode != 0 && need * sizeof(float2) <= ((size_t)16 << 30)) {
         if (need > h->slab_cap) { HIP_TRY(h, dev_realloc(h->slab, need)); h->slab_cap = need; }
-        if (h->n_t > h->tile_cap) { HIP_TRY(h, dev_realloc(h->tile_flag, (size_t)h->n_t)); h->tile_cap = h->n_t; }
-        HIP_TRY(h, hipMemsetAsync(h->tile_flag, 0, sizeof(int) * (size_t)h->n_t, h->stream));
     }
     // cutoff bookkeeping: per-tile box / max speed, and the work list of the symmetric kernel
     h->r_max = 0.f;
@@ -1007,7 +1007,7 @@ static SymArgs make_sym_args(const SfmHandle* h, const TickArgs& a, int tps, int
     const bool lite = a.lite != 0;
     const bool list = a.tile_box && !lite;
     const bool sched = lite && h->cost && h->sched_mode != 0 && (size_t)h->n_t * (size_t)(h->n_t / 2 + 1) <= h->cost_cap;
-    return SymArgs{h->slab, h->tile_flag, h->n_t, slab_stride(h->n_t), h->dpp_dir, debug_steps,
+    return SymArgs{h->slab, h->n_t, slab_stride(h->n_t), h->dpp_dir, debug_steps,
                    (list || sched) ? h->work : nullptr, (list || sched) ? h->work_count : nullptr, lite ? a.tile_box : nullptr,
                    (lite || list) ? a.tile_vmax : nullptr,
                    a.cut_scale, a.cut_pad, stamps, h->strip_box, h->strip_vmax, tps, n_strips,
@@ -1025,10 +1025,9 @@ static int fused_launch(SfmHandle* h, uint32_t flags, int mode, int* sl) {
     const size_t rows = (size_t)n_g * (size_t)h->N_pad;
     TickArgs a;
     fill_args(h, a, flags);
-    static const bool blocked_ok = !(getenv("SFM_FUSED_BLOCKED") && atoi(getenv("SFM_FUSED_BLOCKED")) == 0);      // A/B only
     const FusedArgs f{h->fslab + (size_t)(*sl ^ 1) * rows, h->fslab + (size_t)*sl * rows, h->own, h->own_alt, n_g, h->n_t, h->dpp_dir,
-                      (blocked_ok && n_g % 8 == 0) ? 1 : 0, mode};
-    HIP_TRY(h, launch_fused_tick(h->rad, a, f, h->stream));
+                      (h->fused_blocked != 0 && n_g % 8 == 0) ? 1 : 0, mode};
+    HIP_TRY(h, launch_fused_tick(h->rad, a, f, h->stream, h->fused_waves));
     if (mode != 0) { h->cur ^= 1; std::swap(h->own, h->own_alt); }
     *sl ^= 1;
     return SFM_OK;

@@ -2283,11 +2283,10 @@ hipError_t launch_sym_epilogue(bool rad, const TickArgs& a, const SymArgs& sa, h
 }
 
 // one launch of the fused tick (FusedArgs::mode)
-hipError_t launch_fused_tick(bool rad, const TickArgs& a, const FusedArgs& f, hipStream_t st) {
+hipError_t launch_fused_tick(bool rad, const TickArgs& a, const FusedArgs& f, hipStream_t st, int nw) {
     if (a.N <= 1 || f.n_g < 2) return hipErrorInvalidValue;
     const int n_g = f.n_g, diag = (n_g + 1) / 2;            // diagonal items, full shifts, the half shift of an even n_g
     const dim3 grid(diag + n_g * ((n_g - 1) / 2) + ((n_g & 1) ? 0 : n_g / 2));
-    static const int nw = getenv("SFM_FUSED_WAVES") ? atoi(getenv("SFM_FUSED_WAVES")) : 16;      // A/B only
     if (nw == 8) {
         if (rad) hipLaunchKernelGGL((sfm_fused_tick_kernel<true, 8>), grid, dim3(8 * WAVE), 0, st, a, f);
         else hipLaunchKernelGGL((sfm_fused_tick_kernel<false, 8>), grid, dim3(8 * WAVE), 0, st, a, f);

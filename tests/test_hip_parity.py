@@ -722,6 +722,31 @@ def test_fused_tick_matches_the_two_kernel_tick(n, use_radius, coincide, monkeyp
     assert np.array_equal(wp[same], wp0[same])
 
 
+@pytest.mark.parametrize("waves,blocked", [("8", "1"), ("16", "0")])
+def test_fused_tick_variants_and_pedestrian_force_alone(waves, blocked, monkeypatch):
+    """The fused tick's A/B variants (8-wave workgroups; the plain order of the work items where the XCD-aware one applies) and a
+    crowd with the pedestrian force only (no acceleration force: c4's force set at a size the fused tick takes)."""
+    n = 2048                                                 # 32 tiles, 16 groups: a multiple of 8, so the XCD-aware order is on by default
+    sc = scenarios.make_scenario(n, 99, density=1.0)
+    cfg = default_sfm_config(("pedestrian_force",))
+    out = {}
+    for tag, env in (("variant", {"SFM_FUSED": "1", "SFM_FUSED_WAVES": waves, "SFM_FUSED_BLOCKED": blocked}), ("two-kernel", {"SFM_FUSED": "0"})):
+        for k in ("SFM_FUSED", "SFM_FUSED_WAVES", "SFM_FUSED_BLOCKED"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        eng = SfmEngine(cfg, 0.05)
+        try:
+            eng.upload_state(sc.loc, sc.vel, sc.waypoint, sc.target_speed, sc.radius, None)
+            eng.run(10)
+            assert ("fused" in eng.kernel_variant()) == (tag == "variant")
+            out[tag] = eng.state()
+        finally:
+            eng.close()
+    for a, b in zip(out["variant"][:2], out["two-kernel"][:2]):
+        assert np.isfinite(a).all() and np.abs(a - b).max() < 2e-4
+
+
 def test_fused_runs_carry_on_only_when_nothing_came_between(monkeypatch):
     """A fused run leaves the partial forces of its final state behind, and the next sfm_run / sfm_tick on the handle starts from
     them -- one launch per tick, no launch in front -- but only if it is the very next call.  Whatever comes between (a download,
