@@ -1810,10 +1810,11 @@ __global__ __launch_bounds__(EW * WAVE) void sfm_sym_epilogue_kernel(const TickA
 // fused tick: one launch per tick for a whole planar crowd with the acceleration and pedestrian forces only
 // ------------------------------------------------------------------------------------------------------
 // The two-kernel tick above spends 4.5 of its 19.5 us at N = 4096 on the epilogue launch and the two kernel boundaries around
-// it.  Here the epilogue of tick t is the PROLOGUE of tick t+1's pair kernel: tiles go in groups of two, a workgroup (8 waves)
+// it.  Here the epilogue of tick t is the PROLOGUE of tick t+1's pair kernel: tiles go in groups of two, a workgroup (16 waves)
 // owns one unordered pair of groups (GX, GY) = four tile pairs, or two diagonal groups.  It first integrates its own 256
-// pedestrians from the previous launch's partial forces (a column sum over n_g slab rows, split over the two halves of the
-// workgroup), keeps the new state in LDS, and then runs the systolic steps of sfm_pair_sym_kernel on it: every wave 32 steps.
+// pedestrians from the previous launch's partial forces (a column sum over n_g slab rows, split over the eight 128-thread
+// parts of the workgroup), keeps the new state in LDS, and then runs the systolic steps of sfm_pair_sym_kernel on it: every
+// wave 16 steps.
 // A tile is integrated by every workgroup that needs it -- the same arithmetic on the same operands, hence the same bits --
 // and stored by the workgroup of its group's diagonal item.  No flag, no atomic, no fence: the only synchronisation is the
 // kernel boundary, and state / waypoints / partial forces ping-pong across it.  Grouping tiles by two halves the slab rows a

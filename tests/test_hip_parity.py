@@ -793,6 +793,34 @@ def test_fused_runs_carry_on_only_when_nothing_came_between(monkeypatch):
             assert np.abs(a - b).max() < 2e-4
 
 
+def test_where_the_tile_pair_list_is_built_changes_nothing(monkeypatch):
+    """Whole crowd under the list cutoff with border / obstacle forces: from the second tick on the flat tile-pair list is built by
+    extra workgroups of the geometry launch (boxes and a zeroed counter carried over from the previous epilogue) instead of a
+    launch of its own, and the geometry kernel may run in line or on the side stream.  The items come out in another order; every
+    item still writes its own slab rows, so 70 device-resident ticks (one re-pack inside) end bit-identical either way."""
+    n = 9000
+    sc = scenarios.make_scenario(n, 31337, n_borders=120, n_static=40, n_dynamic=0, density=1.0, border_len=(5.0, 30.0))
+    cfg = default_sfm_config()
+    out = {}
+    for tag, env in (("merged", {}), ("own launch", {"SFM_LIST_MERGE": "0"})):
+        monkeypatch.delenv("SFM_LIST_MERGE", raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        eng = SfmEngine(cfg, 0.05)
+        try:
+            eng.set_borders(sc.borders, sc.border_centers, sc.border_lengths)
+            eng.set_static_obstacles(sc.static_obstacles)
+            eng.upload_state(sc.loc, sc.vel, sc.waypoint, sc.target_speed, sc.radius, None)
+            eng.set_waypoint_stream(sc.seed, sc.world_side, 2.0)
+            eng.run(70, redraw=True)
+            out[tag] = eng.state() + (eng.timing()[2],)
+        finally:
+            eng.close()
+    assert out["merged"][3] < out["own launch"][3]          # fewer launches in the run
+    for a, b in zip(out["merged"][:3], out["own launch"][:3]):
+        assert np.array_equal(a, b)
+
+
 def _arc(center, radius, a0, a1, spacing=0.1):
     n = max(8, int(abs(a1 - a0) * radius / spacing))
     th = np.linspace(a0, a1, n)
