@@ -234,6 +234,7 @@ def main():
         # speed-up is on this line
         e1 = HipShardEngine(cfg, dt, device=local)
         s1 = ShardedStepper(e1, sc)
+        e1.engine.set_timing(False)
         s1.step(args.warmup)
         t1 = timed_windows(s1.step, local_barrier, lambda v: v, args.steps, max(3, args.windows), args.min_seconds)
         single_ref = {"value": args.steps / statistics.median(t1), "unit": "ticks/s", "windows": len(t1),
@@ -257,7 +258,8 @@ def main():
         return float(t.item())
 
     st.exchange()                 # brings the communicator up outside the timed region (idempotent on a fresh state)
-    st.step(args.warmup)
+    eng.engine.set_timing(False)  # the library's own HIP-event bracket of every call (sfm_get_timing) stays out of the timed windows:
+    st.step(args.warmup)          # two event records per call, ~11 us -- 3 % of a 20-tick window of c2
     times = timed_windows(st.step, barrier, reduce_max, args.steps, args.windows, args.min_seconds)
     elapsed = statistics.median(times)
 
@@ -269,6 +271,7 @@ def main():
         raise SystemExit(f"bench.py: state check failed after the timed run on rank {rank} (non-finite or over-speed pedestrians)")
 
     # whole tick on the launch stream (HIP events, no collective in between) ...
+    eng.engine.set_timing(True)
     reps = min(max(args.steps, 1), 200 if sc.n <= 16384 else 10)
     eng.engine.run(reps, redraw=True)
     ev_ms, ev_ticks, ev_launches = eng.engine.timing()

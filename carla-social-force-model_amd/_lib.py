@@ -14,7 +14,7 @@ import numpy as np
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SFM_LIB_PATH") or os.path.join(PKG_DIR, "libsfm_hip.so")   # (the override is for A/B builds of the kernels)
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 FORCE_NAMES = ("acceleration_force", "pedestrian_force", "border_force",
                "static_obstacle_force", "dynamic_obstacle_force")
@@ -77,6 +77,7 @@ SYMBOLS = {
     "sfm_resort": (C.c_int, [_H]),
     "sfm_last_error": (C.c_char_p, [_H]),
     "sfm_get_timing": (C.c_int, [_H, C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "sfm_set_timing": (C.c_int, [_H, C.c_int]),
     "sfm_profile_dominant_kernel": (C.c_int, [_H, C.c_int, C.POINTER(C.c_float)]),
     "sfm_kernel_variant": (C.c_char_p, [_H]),
     "sfm_get_pair_work": (C.c_int, [_H, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),

@@ -196,6 +196,7 @@ struct SfmHandle {
     int split_mode = -1;                   // SFM_SPLIT=0: sfm_tick_begin never does anything (A/B, tests)
     int timed_ticks = 0, timed_launches = 0;
     bool timing_valid = false;
+    bool timing_on = true;                 // sfm_set_timing: the two event records per call cost ~11 us (a 20-tick sfm_run of c2: 3 %)
     int ipw_last = 0;
     int ipw_override = 0, team_override = 0;
     char variant[64] = "none";
@@ -1047,12 +1048,12 @@ static int run_fused(SfmHandle* h, int ticks, uint32_t flags, bool carry) {
     int rc = fused_reserve(h);
     if (rc) return rc;
     snprintf(h->variant, sizeof(h->variant), "sfm_fused_tick_kernel");
-    HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+    if (h->timing_on) HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
     int sl = carry ? h->carry_sl : 0;
     if (!carry) rc = fused_launch(h, flags, 0, &sl);
     for (int t = 0; t < ticks && rc == SFM_OK; ++t) rc = fused_launch(h, flags, 1, &sl);
     if (rc) return rc;
-    HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
+    if (h->timing_on) HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
     h->ticks_since_sort += ticks;
     h->used_fused = true;
     h->carry_ok = true;
@@ -1063,7 +1064,7 @@ static int run_fused(SfmHandle* h, int ticks, uint32_t flags, bool carry) {
     h->count_zeroed = false;
     h->timed_ticks = ticks;
     h->timed_launches = ticks + (carry ? 0 : 1);
-    h->timing_valid = true;
+    h->timing_valid = h->timing_on;
     h->rec_valid = false;
     return SFM_OK;
 }
@@ -1119,7 +1120,7 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags, int phase = PHASE_
         if (!(sym && !whole && list_cut && !h->fsm_on && (flags & SFM_TICK_INTEGRATE) && n_local > 0 && h->split_mode != 0)) return SFM_OK;
         const size_t items = (size_t)h->n_t * (size_t)(h->n_t / 2 + 1);
         if (items > h->work2_cap) { HIP_TRY(h, dev_realloc(h->work2, items)); h->work2_cap = items; }
-        HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+        if (h->timing_on) HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
         ++h->ticks_since_sort;
         TickArgs a;
         fill_args(h, a, flags);
@@ -1149,7 +1150,7 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags, int phase = PHASE_
     if (finishing) snprintf(h->variant, sizeof(h->variant), "sfm_pair_sym_kernel(own|remote)+sfm_sym_epilogue_kernel");
     h->begin_done = false;
     h->last_split = finishing;
-    if (!finishing) HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+    if (!finishing && h->timing_on) HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
     int launches = finishing ? h->timed_launches : 0;
     for (int t = 0; t < ticks; ++t) {
         if (h->reordered && h->resort_every > 0 && (flags & SFM_TICK_INTEGRATE) && h->i_begin == 0 && h->i_end == h->N &&
@@ -1271,10 +1272,10 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags, int phase = PHASE_
             ++launches;
         }
     }
-    HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
+    if (h->timing_on) HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
     h->timed_ticks = ticks;
     h->timed_launches = launches;
-    h->timing_valid = true;
+    h->timing_valid = h->timing_on;
     h->rec_valid = (flags & SFM_TICK_RECORD_FORCES) != 0;
     return SFM_OK;
 }
@@ -1555,10 +1556,18 @@ int sfm_resort(SfmHandle* h) {
 
 const char* sfm_last_error(const SfmHandle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
+int sfm_set_timing(SfmHandle* h, int enable) {
+    if (!h) return SFM_ERR_INVALID;
+    h->carry_ok = false;
+    h->timing_on = enable != 0;
+    if (!h->timing_on) h->timing_valid = false;
+    return SFM_OK;
+}
+
 int sfm_get_timing(SfmHandle* h, float* elapsed_ms, int* ticks, int* launches) {
     int rc = bind(h);
     if (rc) return rc;
-    if (!h->timing_valid) return fail(h, SFM_ERR_STATE, "no timed run yet");
+    if (!h->timing_valid) return fail(h, SFM_ERR_STATE, h->timing_on ? "no timed run yet" : "timing is switched off (sfm_set_timing)");
     HIP_TRY(h, hipEventSynchronize(h->ev1));
     float ms = 0.f;
     HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));

@@ -333,6 +333,10 @@ class SfmEngine:
         """Re-pack the rows spatially now (sfm_resort)."""
         self._check(self._lib.sfm_resort(self._h), "sfm_resort")
 
+    def set_timing(self, enable):
+        """HIP-event bracket of tick()/run() on or off (sfm_set_timing): off saves ~11 us per call; ``timing()`` then raises."""
+        self._check(self._lib.sfm_set_timing(self._h, 1 if enable else 0), "sfm_set_timing")
+
     def timing(self):
         """(elapsed_ms, ticks, launches) of the last tick()/run(), HIP events on the handle's stream."""
         ms, t, l = C.c_float(0), C.c_int(0), C.c_int(0)

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SFM_ABI_VERSION 2   /* 2: + sfm_tick_begin / sfm_tick_end, sfm_set_partition, sfm_get_pair_work (additions only) */
+#define SFM_ABI_VERSION 3   /* 2: + sfm_tick_begin / sfm_tick_end, sfm_set_partition, sfm_get_pair_work; 3: + sfm_set_timing (additions only) */
 
 typedef struct SfmHandle SfmHandle;
 
@@ -225,6 +225,10 @@ const char* sfm_last_error(const SfmHandle* h);
 /* HIP-event time of the last sfm_tick / sfm_run on its stream: total ms, ticks it covered and kernel
  * launches it issued. */
 int sfm_get_timing(SfmHandle* h, float* elapsed_ms, int* ticks, int* launches);
+/* Switches the HIP-event bracket of sfm_tick / sfm_run off (enable = 0) or back on (default): the two event records
+ * cost ~11 us per call, which shows when a call is a few hundred microseconds of work (no reference counterpart: the
+ * reference times nothing).  While off, sfm_get_timing fails with SFM_ERR_STATE. */
+int sfm_set_timing(SfmHandle* h, int enable);
 /* Times the DOMINANT kernel of a tick on its own: `reps` back-to-back launches of the pedestrian-pair kernel the
  * current state would use (the symmetric tile-pair kernel, or the ordered fused tick kernel with flags = 0),
  * bracketed by HIP events on the handle's stream.  The state is not advanced.  For roofline accounting. */

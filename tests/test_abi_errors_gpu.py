@@ -53,6 +53,12 @@ def test_argument_and_state_errors():
         items, terms = C.c_longlong(0), C.c_longlong(0)
         assert lib.sfm_get_pair_work(h, C.byref(items), C.byref(terms)) == -3 and "symmetric" in _err(lib, h)   # one pedestrian: ordered kernel
         assert lib.sfm_tick_begin(h, 0) == 0 and lib.sfm_tick_end(h, 0) == 0                      # not a shard: begin is a no-op, end the whole tick
+        ms, tk, ln = C.c_float(0), C.c_int(0), C.c_int(0)
+        assert lib.sfm_get_timing(h, C.byref(ms), C.byref(tk), C.byref(ln)) == 0 and tk.value == 1 and ln.value >= 1
+        assert lib.sfm_set_timing(h, 0) == 0 and lib.sfm_tick(h, 0) == 0                          # the event bracket off: ticks run, ...
+        assert lib.sfm_get_timing(h, C.byref(ms), C.byref(tk), C.byref(ln)) == -3 and "sfm_set_timing" in _err(lib, h)   # ... nothing to report
+        assert lib.sfm_set_timing(h, 1) == 0 and lib.sfm_tick(h, 0) == 0 and lib.sfm_get_timing(h, C.byref(ms), C.byref(tk), C.byref(ln)) == 0
+        assert lib.sfm_set_timing(None, 1) == -1
     finally:
         assert lib.sfm_destroy(h) == 0
     assert lib.sfm_destroy(None) == 0
