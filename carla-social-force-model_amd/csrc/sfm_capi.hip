@@ -1188,7 +1188,8 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags, int phase = PHASE_
         // (whole crowd with carried boxes: nothing small runs in front of the list / pair kernels any more, their resident grid
         //  takes every wave slot before the side stream's workgroups get in and the two end up back to back behind a cross-stream
         //  wait -- c3 65 us forked against 45 us in line; so up to mid-sized crowds the geometry kernel goes first, on the main
-        //  stream.  From ~1000 tiles on the pair kernel runs for hundreds of microseconds in many rounds of workgroups and the
+        //  stream (the mirror image -- geometry first on the main stream, list + pair kernel on the side stream -- 53 us).  From
+        //  ~1000 tiles on the pair kernel runs for hundreds of microseconds in many rounds of workgroups and the
         //  geometry workgroups do get in between them: c5 825 us in line, 799 us forked.)
         static const int fork_ov = getenv("SFM_FORK") ? atoi(getenv("SFM_FORK")) : -1;      // A/B only: 0 / 1 = in line / side stream with carried boxes
         const bool fork_carried = fork_ov >= 0 ? fork_ov == 1 : h->n_t >= 1024;
