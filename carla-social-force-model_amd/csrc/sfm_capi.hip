@@ -21,6 +21,7 @@ hipError_t launch_sym_list(const TickArgs& a, const SymArgs& sa, hipStream_t st,
 hipError_t launch_sym_pair(bool rad, const TickArgs& a, const SymArgs& sa, hipStream_t st);
 hipError_t launch_sym_epilogue(bool rad, const TickArgs& a, const SymArgs& sa, hipStream_t st);
 hipError_t launch_fused_tick(bool rad, const TickArgs& a, const FusedArgs& f, hipStream_t st, int waves);
+hipError_t launch_sym_pair_geo(bool rad, const TickArgs& a, const SymArgs& sa, hipStream_t st);
 hipError_t launch_schedule(const int* cost, int n_t, uint32_t* work, int* count, hipStream_t st);
 int sym_item_count(int n_t);
 hipError_t launch_strip_bounds(const float4* box, const float* vmax, int n_t, int tps, int n_strips, float4* sbox, float* svmax,
@@ -148,6 +149,7 @@ struct SfmHandle {
     size_t fslab_cap = 0;
     float4* own_alt = nullptr;             // the waypoints ping-pong with the state
     int own_alt_cap = 0;
+    int pair_geo_mode = -1;                // SFM_PAIR_GEO=0: the geometry kernel always gets a launch of its own (A/B, tests)
     int list_merge_mode = -1;              // SFM_LIST_MERGE=0: the flat tile-pair list always gets a launch of its own (A/B, tests)
     int fused_mode = -1;                   // SFM_FUSED=0: always the two-kernel tick (A/B, tests)
     int fused_waves = 16, fused_blocked = 1;   // SFM_FUSED_WAVES=8 / SFM_FUSED_BLOCKED=0: its A/B variants (tests)
@@ -317,6 +319,8 @@ int sfm_create(const SfmParams* params, int device_id, SfmHandle** out) {
     if (ov) h->split_mode = atoi(ov);
     ov = getenv("SFM_GEO_AHEAD");
     if (ov) h->geo_ahead_mode = atoi(ov);
+    ov = getenv("SFM_PAIR_GEO");
+    if (ov) h->pair_geo_mode = atoi(ov);
     ov = getenv("SFM_LIST_MERGE");
     if (ov) h->list_merge_mode = atoi(ov);
     ov = getenv("SFM_FUSED");
@@ -1195,7 +1199,16 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags, int phase = PHASE_
         const bool fork_carried = fork_ov >= 0 ? fork_ov == 1 : h->n_t >= 1024;
         const bool fork = a.geo && n_local > 0 && sym && ((h->overlap_geo && (!(a.tile_box_out && !lite) || fork_carried)) || finishing);
         bool list_in_geo = false;
-        if (ahead) {
+        // whole mid-sized crowd, flat list, boxes and a zeroed counter carried over: the geometry workgroups go into the pair kernel's
+        // launch (sfm_pair_geo_kernel), behind a launch of the list
+        //  (c3: 41.5 -> 35.1 us.  Not with the two-level list of a large crowd: there the geometry kernel on the side stream does
+        //   overlap -- c5 792 us forked, 812 us with 8 192 geometry workgroups in front of the pair kernel's.)
+        const bool geo_in_pair = !ahead && !fork && a.geo && n_local > 0 && sym && whole && carried && h->count_zeroed && list_cut &&
+                                 n_strips == 0 && !finishing && a.en_ped && h->N > 1 && h->debug_steps < 0 && !h->stamps && !h->geo_stamps &&
+                                 h->pair_geo_mode != 0;
+        if (geo_in_pair) a.geo_slices = 4;          // 4 workgroups of 4 waves per tile
+        if (geo_in_pair) {
+        } else if (ahead) {
         } else if (fork) {
             HIP_TRY(h, hipEventRecord(h->ev_fork, h->stream));
             HIP_TRY(h, hipStreamWaitEvent(h->aux, h->ev_fork, 0));
@@ -1232,8 +1245,9 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags, int phase = PHASE_
                 HIP_TRY(h, launch_sym_list(a, sa, h->stream, finishing ? LIST_REMOTE : LIST_ALL, (carried || !whole) && h->count_zeroed));
                 ++launches;
             }
-            HIP_TRY(h, launch_sym_pair(h->rad, a, sa, h->stream));
-            if (fork) HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
+            if (geo_in_pair) HIP_TRY(h, launch_sym_pair_geo(h->rad, a, sa, h->stream));
+            else HIP_TRY(h, launch_sym_pair(h->rad, a, sa, h->stream));
+            if (fork && !geo_in_pair) HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
             SymArgs se = sa;
             if (shard_zero) se.zero_count = 2;
             HIP_TRY(h, launch_sym_epilogue(h->rad, a, se, h->stream));

@@ -516,32 +516,23 @@ __device__ __forceinline__ void list_emit(bool keep, uint32_t item, uint32_t* __
     if (keep) work[s_n[wave] + __popcll(m & ((1ull << lane) - 1ull))] = item;
 }
 
-// GW waves per tile: 16 for up to 1023 tiles (two workgroups per CU: 64 VGPRs, 64 KB of LDS each); 8 from 1024 tiles on --
-// a workgroup's life is a chain of memory round trips, not work, so four thinner workgroups per CU beat two fat ones there.
+template <int GW>
+struct GeoShared {                              // LDS of one geometry workgroup: ~4 KiB per wave
+    float2 row[GW][WAVE];
+    float acc[GW][6][WAVE];
+    GeoItem item[GW][GEO_ITEMS];
+    int count[GW];
+};
+
+// The border / obstacle forces of tile (a.i_begin / 64 + bx), slice slice_y of n_slices: the body of sfm_geometry_kernel, callable
+// from another kernel's workgroups as well (sfm_pair_geo_kernel).  n_bx only places the diagnostic stamps.
 template <bool RAD, int GW>
-__global__ __launch_bounds__(GW * WAVE, 8) void sfm_geometry_kernel(const TickArgs a) {
-    __shared__ float2 s_row[GW][WAVE];
-    __shared__ float s_acc[GW][6][WAVE];
-    __shared__ GeoItem s_item[GW][GEO_ITEMS];
-    __shared__ int s_count[GW];
-    if (a.list_work && (int)blockIdx.x >= a.list_block0) {             // the extra workgroups: the next pair kernel's tile-pair list
-        if (blockIdx.y == 0) {
-            __shared__ int s_n[GW + 1];
-            const int idx = ((int)blockIdx.x - a.list_block0) * (GW * WAVE) + (int)threadIdx.x;     // shift-major, bx fastest
-            const int shift = idx / a.list_n_t;
-            uint32_t item = 0u;
-            const bool keep = shift <= (a.list_n_t >> 1) &&
-                              list_candidate(a.tile_box, a.tile_vmax, a.list_n_t, 0, a.list_n_t, a.ped.lam, a.cut_scale, a.cut_pad,
-                                             PARTNERS_ALL, idx - shift * a.list_n_t, shift, item);
-            list_emit(keep, item, a.list_work, a.list_count, s_n);
-        }
-        return;
-    }
-    const int lane = threadIdx.x & (WAVE - 1);
-    const int wave = uniform((int)(threadIdx.x >> 6));
+__device__ __forceinline__ void geometry_block(const TickArgs& a, GeoShared<GW>& sh, int bx, int slice_y, int n_slices, int n_bx, int tid) {
+    const int lane = tid & (WAVE - 1);
+    const int wave = uniform((int)(tid >> 6));
     unsigned long long st0 = 0, st1 = 0, st2 = 0;
     if (a.geo_stamps) st0 = __builtin_amdgcn_s_memrealtime();
-    const int t = (a.i_begin >> 6) + blockIdx.x;                      // tile index
+    const int t = (a.i_begin >> 6) + bx;                      // tile index
     const int p0 = max(a.i_begin, t * WAVE), p1 = min(a.i_end, (t + 1) * WAVE);
     const int i = t * WAVE + lane;
     GeoLane me;
@@ -571,27 +562,27 @@ __global__ __launch_bounds__(GW * WAVE, 8) void sfm_geometry_kernel(const TickAr
     const float hx = 0.5f * (x1 - x0), hy = 0.5f * (y1 - y0);
     tb.half_diag = sqrtf(fmaf(hx, hx, hy * hy)) * 1.0001f + 1.0e-3f;
     tb.skip_max = skip_max;
-    float2* row = s_row[wave];
+    float2* row = sh.row[wave];
     float f[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
     // ---- phase 1: find
-    const int slice = blockIdx.y;                                      // small crowds: the tile's polylines are split over
-    const int gwave = slice * GW + wave, n_gwaves = GW * (int)gridDim.y;   // gridDim.y workgroups
-    const int n_found = geo_find<RAD, false>(a, me, tb, s_item[wave], row, lane, gwave, n_gwaves, f);
-    if (lane == 0) s_count[wave] = min(n_found, GEO_ITEMS);
+    const int slice = slice_y;                                      // small crowds: the tile's polylines are split over
+    const int gwave = slice * GW + wave, n_gwaves = GW * n_slices;       // n_slices workgroups
+    const int n_found = geo_find<RAD, false>(a, me, tb, sh.item[wave], row, lane, gwave, n_gwaves, f);
+    if (lane == 0) sh.count[wave] = min(n_found, GEO_ITEMS);
     __syncthreads();
     if (a.geo_stamps) st1 = __builtin_amdgcn_s_memrealtime();
 
     // ---- phase 2: scan, items dealt round-robin in (wave, index) order
     {
-        int w = 0, first = 0, cnt = s_count[0];                       // items [first, first + cnt) belong to list w
+        int w = 0, first = 0, cnt = sh.count[0];                       // items [first, first + cnt) belong to list w
         int total = 0;
 #pragma unroll
-        for (int q = 0; q < GW; ++q) total += s_count[q];
+        for (int q = 0; q < GW; ++q) total += sh.count[q];
         total = uniform(total);
         for (int j = wave; j < total; j += GW) {
-            while (j >= first + cnt) { first += cnt; ++w; cnt = s_count[w]; }
-            const GeoItem it = s_item[uniform(w)][uniform(j - first)];
+            while (j >= first + cnt) { first += cnt; ++w; cnt = sh.count[w]; }
+            const GeoItem it = sh.item[uniform(w)][uniform(j - first)];
             GeoItem u = it;
             u.o0 = uniform(it.o0); u.o1 = uniform(it.o1); u.kind = uniform(it.kind);
             const bool keep = geo_keep(a, me, u.kind, u.c, u.s0, u.s1);
@@ -600,23 +591,44 @@ __global__ __launch_bounds__(GW * WAVE, 8) void sfm_geometry_kernel(const TickAr
     }
     // ---- list overflow (a tile whose pedestrians are spread over the whole map): this wave walks its polylines
     // again and scans, on the spot, the kept ones that did not fit
-    if (n_found > GEO_ITEMS) geo_find<RAD, true>(a, me, tb, s_item[wave], row, lane, gwave, n_gwaves, f);
+    if (n_found > GEO_ITEMS) geo_find<RAD, true>(a, me, tb, sh.item[wave], row, lane, gwave, n_gwaves, f);
 #pragma unroll
-    for (int q = 0; q < 6; ++q) s_acc[wave][q][lane] = f[q];
+    for (int q = 0; q < 6; ++q) sh.acc[wave][q][lane] = f[q];
     __syncthreads();
     if (a.geo_stamps) st2 = __builtin_amdgcn_s_memrealtime();
-    if (wave < 6 && me.live) {                                         // wave w finishes component w
+    for (int q = wave; q < 6 && me.live; q += GW) {                    // wave w finishes component w (and w + GW)
         float v = 0.0f;
 #pragma unroll
-        for (int w = 0; w < GW; ++w) v += s_acc[w][wave][lane];
-        if (wave >= 4) v *= a.dyn.negA;
-        else if (wave >= 2) v *= a.stat.negA;
-        a.geo[((size_t)slice * 6 + wave) * a.N_pad + i] = v;
+        for (int w = 0; w < GW; ++w) v += sh.acc[w][q][lane];
+        if (q >= 4) v *= a.dyn.negA;
+        else if (q >= 2) v *= a.stat.negA;
+        a.geo[((size_t)slice * 6 + q) * a.N_pad + i] = v;
     }
-    if (a.geo_stamps && threadIdx.x == 0) {
-        unsigned long long* o = a.geo_stamps + 4 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
+    if (a.geo_stamps && tid == 0) {
+        unsigned long long* o = a.geo_stamps + 4 * ((size_t)slice_y * n_bx + bx);
         o[0] = st0; o[1] = st1; o[2] = st2; o[3] = __builtin_amdgcn_s_memrealtime();
     }
+}
+
+// GW waves per tile: 16 for up to 1023 tiles (two workgroups per CU: 64 VGPRs, 64 KB of LDS each); 8 from 1024 tiles on --
+// a workgroup's life is a chain of memory round trips, not work, so four thinner workgroups per CU beat two fat ones there.
+template <bool RAD, int GW>
+__global__ __launch_bounds__(GW * WAVE, 8) void sfm_geometry_kernel(const TickArgs a) {
+    __shared__ GeoShared<GW> sh;
+    if (a.list_work && (int)blockIdx.x >= a.list_block0) {             // the extra workgroups: the next pair kernel's tile-pair list
+        if (blockIdx.y == 0) {
+            __shared__ int s_n[GW + 1];
+            const int idx = ((int)blockIdx.x - a.list_block0) * (GW * WAVE) + (int)threadIdx.x;     // shift-major, bx fastest
+            const int shift = idx / a.list_n_t;
+            uint32_t item = 0u;
+            const bool keep = shift <= (a.list_n_t >> 1) &&
+                              list_candidate(a.tile_box, a.tile_vmax, a.list_n_t, 0, a.list_n_t, a.ped.lam, a.cut_scale, a.cut_pad,
+                                             PARTNERS_ALL, idx - shift * a.list_n_t, shift, item);
+            list_emit(keep, item, a.list_work, a.list_count, s_n);
+        }
+        return;
+    }
+    geometry_block<RAD, GW>(a, sh, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y, (int)gridDim.x, (int)threadIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1305,17 +1317,17 @@ __global__ void sfm_dpp_probe_kernel(int* out) {       // which way does wave_ro
     out[lane] = __builtin_amdgcn_update_dpp(0, lane, 0x134, 0xf, 0xf, false);
 }
 
-// CUT: the provably negligible part of a tile pair is not evaluated (DESIGN.md 3.5).  reach = the distance beyond which a
-// term is below 2^-40 A given the largest speeds of the two tiles (tiles_negligible's bound, per pair instead of per box):
-// a systolic step whose 64 pairs are ALL farther apart than that costs two subtractions, two fmas, a compare and the
-// rotation.  The test is on the pair's own distance, so it needs no agreement with anything else.
+struct PairShared {                             // LDS of one pair workgroup
+    float2 fi[WAVES_PER_BLOCK][WAVE];
+    float2 fj[WAVES_PER_BLOCK][WAVE];
+    int cnt[WAVES_PER_BLOCK];
+};
+
+// The body of sfm_pair_sym_kernel for workgroup (bid_x, bid_y) of a grid grid_x wide, callable from another kernel's workgroups as
+// well (sfm_pair_geo_kernel).
 template <bool RAD, bool CUT>
-__global__ __launch_bounds__(BLOCK) void sfm_pair_sym_kernel(const float4* __restrict__ pk, const float* __restrict__ radius,
-                                                             const IxConst c, const SymArgs sa) {
-    __shared__ float2 s_fi[WAVES_PER_BLOCK][WAVE];
-    __shared__ float2 s_fj[WAVES_PER_BLOCK][WAVE];
-    __shared__ int s_cnt[WAVES_PER_BLOCK];
-    const int tid = threadIdx.x;
+__device__ __forceinline__ void pair_block(const float4* __restrict__ pk, const float* __restrict__ radius, const IxConst& c, const SymArgs& sa,
+                                           PairShared& sh, int bid_x, int bid_y, int grid_x, int tid) {
     const int lane = tid & (WAVE - 1);
     const int wave = uniform(tid >> 6);
     const int n_t = sa.n_t;
@@ -1326,10 +1338,10 @@ __global__ __launch_bounds__(BLOCK) void sfm_pair_sym_kernel(const float4* __res
     const int n_items = sa.work ? *sa.work_count : 1;
     // list mode: a workgroup takes a contiguous run of the list (consecutive items share a tile: its rows stay hot in this
     // CU's cache and no two workgroups hammer the same lines at the same moment)
-    const int run = sa.work ? (n_items + (int)gridDim.x - 1) / (int)gridDim.x : 1;
-    const int item0 = sa.work ? (int)blockIdx.x * run : 0;
+    const int run = sa.work ? (n_items + grid_x - 1) / grid_x : 1;
+    const int item0 = sa.work ? bid_x * run : 0;
   for (int item = item0; item < min(n_items, item0 + run); ++item) {
-    int shift = blockIdx.y, bx = blockIdx.x;      // shift = tile distance: 0 = diagonal items
+    int shift = bid_y, bx = bid_x;      // shift = tile distance: 0 = diagonal items
     bool one_sided = false;                       // tb belongs to another rank: only tile ta's side is kept
     if (sa.work) {
         const uint32_t w = sa.work[item];
@@ -1417,11 +1429,11 @@ __global__ __launch_bounds__(BLOCK) void sfm_pair_sym_kernel(const float4* __res
         i_end_loc = (lane + sa.dir * (sig0 + nsteps)) & (WAVE - 1);
       }
     }
-    s_fi[wave][i_end_loc] = make_float2(fxi, fyi);
-    s_fj[wave][lane] = make_float2(fxj, fyj);
-    if (sa.cost && lane == 0) s_cnt[wave] = executed;
+    sh.fi[wave][i_end_loc] = make_float2(fxi, fyi);
+    sh.fj[wave][lane] = make_float2(fxj, fyj);
+    if (sa.cost && lane == 0) sh.cnt[wave] = executed;
     __syncthreads();
-    if (sa.cost && tid == 0) sa.cost[shift * n_t + bx] = (s_cnt[0] + s_cnt[1]) + (s_cnt[2] + s_cnt[3]);
+    if (sa.cost && tid == 0) sa.cost[shift * n_t + bx] = (sh.cnt[0] + sh.cnt[1]) + (sh.cnt[2] + sh.cnt[3]);
     if (negligible) {
         // nothing written: the epilogue applies the same (bitwise symmetric) test and does not read this pair's slab rows
     } else if (shift == 0) {
@@ -1431,7 +1443,7 @@ __global__ __launch_bounds__(BLOCK) void sfm_pair_sym_kernel(const float4* __res
             const int t = (g == 0) ? bx : bx + half_up;
             if (t < sa.t_hi) {
                 const int p = tid & (WAVE - 1);
-                const float2 a0 = s_fi[2 * g][p], a1 = s_fi[2 * g + 1][p], b0 = s_fj[2 * g][p], b1 = s_fj[2 * g + 1][p];
+                const float2 a0 = sh.fi[2 * g][p], a1 = sh.fi[2 * g + 1][p], b0 = sh.fj[2 * g][p], b1 = sh.fj[2 * g + 1][p];
                 sa.slab[(size_t)t * sa.stride + t * WAVE + p] = make_float2(((a0.x + a1.x) + b0.x) + b1.x,
                                                                             ((a0.y + a1.y) + b0.y) + b1.y);
             }
@@ -1439,17 +1451,17 @@ __global__ __launch_bounds__(BLOCK) void sfm_pair_sym_kernel(const float4* __res
     } else if (tid < 2 * WAVE) {
         const int p = tid & (WAVE - 1);
         if (tid < WAVE) {     // force on tile ta's pedestrians from tile tb
-            const float2 a0 = s_fi[0][p], a1 = s_fi[1][p], a2 = s_fi[2][p], a3 = s_fi[3][p];
+            const float2 a0 = sh.fi[0][p], a1 = sh.fi[1][p], a2 = sh.fi[2][p], a3 = sh.fi[3][p];
             sa.slab[(size_t)tb * sa.stride + ta * WAVE + p] = make_float2(((a0.x + a1.x) + a2.x) + a3.x, ((a0.y + a1.y) + a2.y) + a3.y);
         } else if (!one_sided) {   // force on tile tb's pedestrians from tile ta
-            const float2 a0 = s_fj[0][p], a1 = s_fj[1][p], a2 = s_fj[2][p], a3 = s_fj[3][p];
+            const float2 a0 = sh.fj[0][p], a1 = sh.fj[1][p], a2 = sh.fj[2][p], a3 = sh.fj[3][p];
             sa.slab[(size_t)ta * sa.stride + tb * WAVE + p] = make_float2(((a0.x + a1.x) + a2.x) + a3.x, ((a0.y + a1.y) + a2.y) + a3.y);
         }
     }
     if (sa.work) __syncthreads();                 // LDS is reused by the next item
   }
-    if (sa.stamps && threadIdx.x == 0) {
-        const size_t b = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    if (sa.stamps && tid == 0) {
+        const size_t b = (size_t)bid_y * grid_x + bid_x;
         unsigned hw;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         unsigned xcc;
@@ -1457,6 +1469,36 @@ __global__ __launch_bounds__(BLOCK) void sfm_pair_sym_kernel(const float4* __res
         sa.stamps[3 * b] = t_start;
         sa.stamps[3 * b + 1] = __builtin_amdgcn_s_memrealtime();
         sa.stamps[3 * b + 2] = ((unsigned long long)xcc << 32) | hw;
+    }
+}
+
+// CUT: the provably negligible part of a tile pair is not evaluated (DESIGN.md 3.5).  reach = the distance beyond which a
+// term is below 2^-40 A given the largest speeds of the two tiles (tiles_negligible's bound, per pair instead of per box):
+// a systolic step whose 64 pairs are ALL farther apart than that costs two subtractions, two fmas, a compare and the
+// rotation.  The test is on the pair's own distance, so it needs no agreement with anything else.
+template <bool RAD, bool CUT>
+__global__ __launch_bounds__(BLOCK) void sfm_pair_sym_kernel(const float4* __restrict__ pk, const float* __restrict__ radius,
+                                                             const IxConst c, const SymArgs sa) {
+    __shared__ PairShared sh;
+    pair_block<RAD, CUT>(pk, radius, c, sa, sh, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x, (int)threadIdx.x);
+}
+
+// Geometry workgroups in front of the pair kernel's workgroups in ONE launch (whole mid-sized crowd, list cutoff): the border /
+// obstacle forces only need the tick's input state and their workgroups are chains of memory round trips, the pair workgroups
+// are VALU work -- side by side on the CUs they overlap, which two launches on two streams do not at this size.
+// The geometry part runs as 4-wave workgroups, geo_slices of them per tile (the same 16 waves per tile as sfm_geometry_kernel),
+// so that both kinds share the block size; they come first in the grid and are therefore dispatched first.
+template <bool RAD>
+__global__ __launch_bounds__(BLOCK) void sfm_pair_geo_kernel(const TickArgs a, const SymArgs sa, int geo_tiles) {
+    constexpr size_t LDS = sizeof(GeoShared<WAVES_PER_BLOCK>) > sizeof(PairShared) ? sizeof(GeoShared<WAVES_PER_BLOCK>) : sizeof(PairShared);
+    __shared__ __attribute__((aligned(16))) char smem[LDS];
+    const int n_geo = geo_tiles * a.geo_slices;
+    if ((int)blockIdx.x < n_geo) {
+        geometry_block<RAD, WAVES_PER_BLOCK>(a, *reinterpret_cast<GeoShared<WAVES_PER_BLOCK>*>(smem), (int)blockIdx.x % geo_tiles,
+                                             (int)blockIdx.x / geo_tiles, a.geo_slices, geo_tiles, (int)threadIdx.x);
+    } else {
+        pair_block<RAD, true>(a.pk_cur, a.radius, a.ped, sa, *reinterpret_cast<PairShared*>(smem), (int)blockIdx.x - n_geo, 0,
+                              (int)gridDim.x - n_geo, (int)threadIdx.x);
     }
 }
 
@@ -2234,6 +2276,16 @@ hipError_t launch_sym_pair(bool rad, const TickArgs& a, const SymArgs& sa, hipSt
     const bool cut = sa.vmax != nullptr;           // list or lite cutoff: the per-step reach test is on as well
     if (rad) { if (cut) launch_sym_pair_t<true, true>(grid, a, sa, st); else launch_sym_pair_t<true, false>(grid, a, sa, st); }
     else { if (cut) launch_sym_pair_t<false, true>(grid, a, sa, st); else launch_sym_pair_t<false, false>(grid, a, sa, st); }
+    return hipGetLastError();
+}
+
+// the pair kernel of a list-cutoff tick with the geometry workgroups of the same tick in front (sfm_pair_geo_kernel)
+hipError_t launch_sym_pair_geo(bool rad, const TickArgs& a, const SymArgs& sa, hipStream_t st) {
+    const int tiles = ((a.i_end + WAVE - 1) >> 6) - (a.i_begin >> 6);
+    const int rounds = std::min(16, std::max(2, sa.n_t / 64));
+    const dim3 grid(tiles * a.geo_slices + 256 * 8 * rounds);
+    if (rad) hipLaunchKernelGGL((sfm_pair_geo_kernel<true>), grid, dim3(BLOCK), 0, st, a, sa, tiles);
+    else hipLaunchKernelGGL((sfm_pair_geo_kernel<false>), grid, dim3(BLOCK), 0, st, a, sa, tiles);
     return hipGetLastError();
 }
 
