@@ -793,7 +793,8 @@ def test_fused_runs_carry_on_only_when_nothing_came_between(monkeypatch):
             assert np.abs(a - b).max() < 2e-4
 
 
-def test_which_launch_hosts_the_list_and_the_geometry_changes_nothing(monkeypatch):
+@pytest.mark.parametrize("use_radius", [False, True])
+def test_which_launch_hosts_the_list_and_the_geometry_changes_nothing(use_radius, monkeypatch):
     """Whole crowd under the list cutoff with border / obstacle forces.  From the second tick on (boxes and a zeroed list counter
     carried over from the previous epilogue) a tick is three launches, in one of two arrangements: list -> pair kernel with the
     geometry workgroups in front (sfm_pair_geo_kernel, the default) -> epilogue, or geometry kernel whose extra workgroups build
@@ -802,8 +803,9 @@ def test_which_launch_hosts_the_list_and_the_geometry_changes_nothing(monkeypatc
     runs are bit-identical after 70 device-resident ticks (one re-pack inside); the geometry workgroups inside the pair launch
     sum a tile's polylines in four slices instead of one, so that run agrees to rounding."""
     n = 9000
-    sc = scenarios.make_scenario(n, 31337, n_borders=120, n_static=40, n_dynamic=0, density=1.0, border_len=(5.0, 30.0))
+    sc = scenarios.make_scenario(n, 31337, n_borders=120, n_static=40, n_dynamic=6, density=0.25 if use_radius else 1.0, border_len=(5.0, 30.0))
     cfg = default_sfm_config()
+    cfg["use_ped_radius"] = use_radius
     out = {}
     for tag, env in (("geometry in the pair launch", {}), ("list in the geometry launch", {"SFM_PAIR_GEO": "0"}),
                      ("own launches", {"SFM_PAIR_GEO": "0", "SFM_LIST_MERGE": "0"})):
@@ -815,6 +817,7 @@ def test_which_launch_hosts_the_list_and_the_geometry_changes_nothing(monkeypatc
         try:
             eng.set_borders(sc.borders, sc.border_centers, sc.border_lengths)
             eng.set_static_obstacles(sc.static_obstacles)
+            eng.set_dynamic_boxes([c for c, _ in sc.dynamic_obstacles], sc.dynamic_yaw, sc.dynamic_extent, sc.dynamic_vel)   # vehicles move on the device
             eng.upload_state(sc.loc, sc.vel, sc.waypoint, sc.target_speed, sc.radius, None)
             eng.set_waypoint_stream(sc.seed, sc.world_side, 2.0)
             eng.run(12, redraw=True)
@@ -823,7 +826,10 @@ def test_which_launch_hosts_the_list_and_the_geometry_changes_nothing(monkeypatc
             out[tag] = eng.state() + (eng.timing()[2], early)
         finally:
             eng.close()
-    assert out["geometry in the pair launch"][3] == out["list in the geometry launch"][3] < out["own launches"][3]
+    if use_radius:      # (the epilogue does not carry boxes for use_ped_radius: every arrangement is the uncarried tick, launch for launch)
+        assert out["geometry in the pair launch"][3] == out["list in the geometry launch"][3] == out["own launches"][3]
+    else:
+        assert out["geometry in the pair launch"][3] == out["list in the geometry launch"][3] < out["own launches"][3]
     for a, b in zip(out["list in the geometry launch"][:3], out["own launches"][:3]):
         assert np.array_equal(a, b)
     # (rounding differences grow along a trajectory: compared after 12 ticks; the arrangement itself is checked against the oracle
