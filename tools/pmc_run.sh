@@ -8,6 +8,9 @@ root=$GRAFT_REPO_ROOT
 out=$root/gpurun_out/pmc_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
+# the counters are those of the pedestrian-pair kernel ON ITS OWN (what bench.py times alone with HIP events): the geometry
+# workgroups stay in a launch of their own for these passes
+export SFM_PAIR_GEO=0
 specs=""
 for w in $wl; do
   t=40; [ $w = c5 ] && t=12
