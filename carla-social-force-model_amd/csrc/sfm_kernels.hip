@@ -1,19 +1,22 @@
-// sfm_kernels.hip -- the fused Social-Force-Model tick for gfx950 (MI355X), hand-written HIP.
+// sfm_kernels.hip -- the Social-Force-Model tick for gfx950 (MI355X), hand-written HIP.  DESIGN.md section 3 is the map.
 //
-// One launch = one tick of PedestrianSimulation.tick's numeric part (pedestrian_simulation.py:81-83):
+// A tick is the numeric part of PedestrianSimulation.tick (pedestrian_simulation.py:81-83):
 //   F_i = acceleration + pedestrian (N x N Moussaid) + border + static + dynamic obstacle forces,
 //   v'  = cap(v + dt*F, 1.3*v_target),  optionally x' = x + dt*v' and arrival -> next waypoint.
 //
-// Mapping (wave = 64 lanes, 4 waves per workgroup):
-//   * a WAVE owns IPW consecutive pedestrians i; their {x,y,vx,vy} live in SGPRs (wave-uniform);
-//   * the 64 LANES span j: the workgroup stages tiles of 256 packed records {x,y,vx,vy} (16 B, one
-//     coalesced float4 per thread) from HBM/L2 into LDS, double-buffered, one barrier per tile; every wave
-//     reads its lane's record with one conflict-free ds_read_b128 per 64*IPW pairs;
-//   * per-lane partial force sums live in VGPRs and are reduced across the wave with shuffles once per tick
-//     (deterministic order, no atomics);  the same wave then runs the border / obstacle culls and
-//     nearest-point scans (lanes over polylines, then over points) and the O(1) epilogue for its
-//     pedestrians, so F never touches HBM.
-// No MFMA: the pair body is ~60 dependent VALU ops with 5 transcendentals, not a contraction.
+// Kernels, in file order:
+//   sfm_geometry_kernel        border / obstacle forces: a workgroup per tile of 64 pedestrians (x slices), find then scan
+//   sfm_mode_kernel            pedestrian modes, waypoint queues, gap acceptance (device-resident runs)
+//   sfm_tick_kernel            ORDERED tick, fully fused: a wave owns IPW pedestrians (state in SGPRs), the lanes span j; 3-D
+//                              crowds, crowds under 256 pedestrians, ragged shards
+//   sfm_tile_bounds / strip_bounds / tile_strip_bounds, sfm_pair_list / list2
+//                              boxes and the tile-pair list of the "provably < 2^-40 A" cutoff
+//   sfm_pair_sym_kernel        SYMMETRIC pair kernel: every unordered pair once, systolic over the wavefront (DPP rotate)
+//   sfm_pair_geo_kernel        the same with the tick's geometry workgroups in front, in one launch
+//   sfm_sym_epilogue_kernel    column sums of the slab + integration for the symmetric path
+//   sfm_fused_tick_kernel      one launch per tick: the epilogue of tick t as the prologue of tick t+1's pair kernel
+// No MFMA: the pair body is ~60 dependent VALU ops with 5 transcendentals, not a contraction.  No atomics on forces, fixed
+// summation orders: every result is deterministic run to run.
 #include "sfm_device.h"
 
 #include <algorithm>
