@@ -1197,16 +1197,18 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags, int phase = PHASE_
         //  geometry workgroups do get in between them: c5 825 us in line, 799 us forked.)
         static const int fork_ov = getenv("SFM_FORK") ? atoi(getenv("SFM_FORK")) : -1;      // A/B only: 0 / 1 = in line / side stream with carried boxes
         const bool fork_carried = fork_ov >= 0 ? fork_ov == 1 : h->n_t >= 1024;
-        const bool fork = a.geo && n_local > 0 && sym && ((h->overlap_geo && (!(a.tile_box_out && !lite) || fork_carried)) || finishing);
+        // Whole crowd under the list cutoff, boxes and a zeroed list counter carried over: the geometry workgroups go into the pair
+        // kernel's launch (sfm_pair_geo_kernel) behind the launch(es) of the list, and overlap with the pair workgroups on the CUs.
+        // Mid-sized crowd: four 4-wave workgroups per tile, first in the grid -- c3 41.5 -> 35.1 us.  Large crowd (two-level list):
+        // one 4-wave workgroup per tile, spread evenly over the grid -- c5 792 us with the geometry kernel on the side stream,
+        // 778 us this way (812 us with 8 192 of them in front of the pair workgroups: they hold every slot for four rounds).
+        const bool geo_in_pair = !ahead && a.geo && n_local > 0 && sym && whole && carried && h->count_zeroed && list_cut && !finishing &&
+                                 a.en_ped && h->N > 1 && h->debug_steps < 0 && !h->stamps && !h->geo_stamps && h->pair_geo_mode != 0;
+        const bool fork = !geo_in_pair && a.geo && n_local > 0 && sym &&
+                          ((h->overlap_geo && (!(a.tile_box_out && !lite) || fork_carried)) || finishing);
         bool list_in_geo = false;
-        // whole mid-sized crowd, flat list, boxes and a zeroed counter carried over: the geometry workgroups go into the pair kernel's
-        // launch (sfm_pair_geo_kernel), behind a launch of the list
-        //  (c3: 41.5 -> 35.1 us.  Not with the two-level list of a large crowd: there the geometry kernel on the side stream does
-        //   overlap -- c5 792 us forked, 812 us with 8 192 geometry workgroups in front of the pair kernel's.)
-        const bool geo_in_pair = !ahead && !fork && a.geo && n_local > 0 && sym && whole && carried && h->count_zeroed && list_cut &&
-                                 n_strips == 0 && !finishing && a.en_ped && h->N > 1 && h->debug_steps < 0 && !h->stamps && !h->geo_stamps &&
-                                 h->pair_geo_mode != 0;
-        if (geo_in_pair) a.geo_slices = 4;          // 4 workgroups of 4 waves per tile
+        static const int pg_slices = getenv("SFM_PG_SLICES") ? atoi(getenv("SFM_PG_SLICES")) : 0;      // A/B only
+        if (geo_in_pair) a.geo_slices = pg_slices > 0 ? pg_slices : (h->n_t >= 1024 ? 1 : 4);
         if (geo_in_pair) {
         } else if (ahead) {
         } else if (fork) {
@@ -1247,7 +1249,7 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags, int phase = PHASE_
             }
             if (geo_in_pair) HIP_TRY(h, launch_sym_pair_geo(h->rad, a, sa, h->stream));
             else HIP_TRY(h, launch_sym_pair(h->rad, a, sa, h->stream));
-            if (fork && !geo_in_pair) HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
+            if (fork) HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
             SymArgs se = sa;
             if (shard_zero) se.zero_count = 2;
             HIP_TRY(h, launch_sym_epilogue(h->rad, a, se, h->stream));

@@ -1492,15 +1492,21 @@ __global__ __launch_bounds__(BLOCK) void sfm_pair_sym_kernel(const float4* __res
 // The geometry part runs as 4-wave workgroups, geo_slices of them per tile (the same 16 waves per tile as sfm_geometry_kernel),
 // so that both kinds share the block size; they come first in the grid and are therefore dispatched first.
 template <bool RAD>
-__global__ __launch_bounds__(BLOCK) void sfm_pair_geo_kernel(const TickArgs a, const SymArgs sa, int geo_tiles) {
+__global__ __launch_bounds__(BLOCK) void sfm_pair_geo_kernel(const TickArgs a, const SymArgs sa, int geo_tiles, int geo_stride) {
     constexpr size_t LDS = sizeof(GeoShared<WAVES_PER_BLOCK>) > sizeof(PairShared) ? sizeof(GeoShared<WAVES_PER_BLOCK>) : sizeof(PairShared);
     __shared__ __attribute__((aligned(16))) char smem[LDS];
     const int n_geo = geo_tiles * a.geo_slices;
-    if ((int)blockIdx.x < n_geo) {
-        geometry_block<RAD, WAVES_PER_BLOCK>(a, *reinterpret_cast<GeoShared<WAVES_PER_BLOCK>*>(smem), (int)blockIdx.x % geo_tiles,
-                                             (int)blockIdx.x / geo_tiles, a.geo_slices, geo_tiles, (int)threadIdx.x);
+    // geo_stride 1: the geometry workgroups come first (they take half the wave slots of a mid-sized crowd's first round);
+    // geo_stride s > 1: every s-th workgroup of the grid is one of them -- a large crowd has several rounds of them, and in front
+    // of the pair workgroups they would hold every slot for those rounds
+    const int bid = (int)blockIdx.x;
+    const int g = bid / geo_stride;
+    const bool is_geo = g < n_geo && bid == g * geo_stride;
+    if (is_geo) {
+        geometry_block<RAD, WAVES_PER_BLOCK>(a, *reinterpret_cast<GeoShared<WAVES_PER_BLOCK>*>(smem), g % geo_tiles, g / geo_tiles, a.geo_slices,
+                                             geo_tiles, (int)threadIdx.x);
     } else {
-        pair_block<RAD, true>(a.pk_cur, a.radius, a.ped, sa, *reinterpret_cast<PairShared*>(smem), (int)blockIdx.x - n_geo, 0,
+        pair_block<RAD, true>(a.pk_cur, a.radius, a.ped, sa, *reinterpret_cast<PairShared*>(smem), bid - min(n_geo, g + 1), 0,
                               (int)gridDim.x - n_geo, (int)threadIdx.x);
     }
 }
@@ -2286,9 +2292,14 @@ hipError_t launch_sym_pair(bool rad, const TickArgs& a, const SymArgs& sa, hipSt
 hipError_t launch_sym_pair_geo(bool rad, const TickArgs& a, const SymArgs& sa, hipStream_t st) {
     const int tiles = ((a.i_end + WAVE - 1) >> 6) - (a.i_begin >> 6);
     const int rounds = std::min(16, std::max(2, sa.n_t / 64));
-    const dim3 grid(tiles * a.geo_slices + 256 * 8 * rounds);
-    if (rad) hipLaunchKernelGGL((sfm_pair_geo_kernel<true>), grid, dim3(BLOCK), 0, st, a, sa, tiles);
-    else hipLaunchKernelGGL((sfm_pair_geo_kernel<false>), grid, dim3(BLOCK), 0, st, a, sa, tiles);
+    const int n_geo = tiles * a.geo_slices, n_pair = 256 * 8 * rounds;
+    const dim3 grid(n_geo + n_pair);
+    // more geometry workgroups than the CUs hold in one round beside the pair workgroups: spread them evenly over the grid
+    static const int stride_ov = getenv("SFM_PG_STRIDE") ? atoi(getenv("SFM_PG_STRIDE")) : 0;      // A/B only
+    int stride = n_geo > 256 * 4 ? std::max(1, (n_geo + n_pair) / n_geo) : 1;
+    if (stride_ov > 0) stride = std::min(stride_ov, std::max(1, (n_geo + n_pair) / n_geo));
+    if (rad) hipLaunchKernelGGL((sfm_pair_geo_kernel<true>), grid, dim3(BLOCK), 0, st, a, sa, tiles, stride);
+    else hipLaunchKernelGGL((sfm_pair_geo_kernel<false>), grid, dim3(BLOCK), 0, st, a, sa, tiles, stride);
     return hipGetLastError();
 }
 
