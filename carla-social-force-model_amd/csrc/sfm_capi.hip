@@ -933,7 +933,9 @@ static void fill_args(SfmHandle* h, TickArgs& a, uint32_t flags) {
     a.tile_vmax = (cut || lite) ? h->tile_vmax + (size_t)h->box_cur * h->n_t : nullptr;
     // whole crowd on the symmetric path: the epilogue leaves the next tick's boxes (and, list cutoff, a zeroed list counter), so
     // the next tick starts with its list kernel instead of a bounds kernel and a memset
-    const bool carry = lite || (cut && lite_ok && h->carry_mode != 0 && !h->fsm_on);
+    // (the boxes do not depend on the radii -- cut_pad carries 2 r_max into every test -- so use_ped_radius crowds carry them too)
+    const bool carry = lite || (cut && (lite_ok || (h->rad && p.enabled[SFM_FORCE_PEDESTRIAN] && h->tile_box && !h->z3 && h->slab && h->i_begin == 0 &&
+                                                  h->i_end == h->N && h->sym_mode != 0)) && h->carry_mode != 0 && !h->fsm_on);
     a.tile_box_out = carry ? h->tile_box + (size_t)(h->box_cur ^ 1) * h->n_t : nullptr;
     a.tile_vmax_out = carry ? h->tile_vmax + (size_t)(h->box_cur ^ 1) * h->n_t : nullptr;
     a.lite = lite ? 1 : 0;

@@ -808,8 +808,8 @@ def test_which_launch_hosts_the_list_and_the_geometry_changes_nothing(use_radius
     cfg["use_ped_radius"] = use_radius
     out = {}
     for tag, env in (("geometry in the pair launch", {}), ("list in the geometry launch", {"SFM_PAIR_GEO": "0"}),
-                     ("own launches", {"SFM_PAIR_GEO": "0", "SFM_LIST_MERGE": "0"})):
-        for k in ("SFM_PAIR_GEO", "SFM_LIST_MERGE"):
+                     ("own launches", {"SFM_PAIR_GEO": "0", "SFM_LIST_MERGE": "0"}), ("nothing carried", {"SFM_CARRY": "0"})):
+        for k in ("SFM_PAIR_GEO", "SFM_LIST_MERGE", "SFM_CARRY"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -826,15 +826,16 @@ def test_which_launch_hosts_the_list_and_the_geometry_changes_nothing(use_radius
             out[tag] = eng.state() + (eng.timing()[2], early)
         finally:
             eng.close()
-    if use_radius:      # (the epilogue does not carry boxes for use_ped_radius: every arrangement is the uncarried tick, launch for launch)
-        assert out["geometry in the pair launch"][3] == out["list in the geometry launch"][3] == out["own launches"][3]
-    else:
-        assert out["geometry in the pair launch"][3] == out["list in the geometry launch"][3] < out["own launches"][3]
+    assert out["geometry in the pair launch"][3] == out["list in the geometry launch"][3] < out["own launches"][3]
     for a, b in zip(out["list in the geometry launch"][:3], out["own launches"][:3]):
         assert np.array_equal(a, b)
     # (rounding differences grow along a trajectory: compared after 12 ticks; the arrangement itself is checked against the oracle
     #  by the full-size c3 test, whose ticks 4 and 134 run it)
     for a, b in zip(out["geometry in the pair launch"][4][:2], out["own launches"][4][:2]):
+        assert np.isfinite(a).all() and np.abs(a - b).max() < 2e-4
+    # ... and the tick that carries nothing over (boxes from sfm_tile_bounds_kernel every tick, geometry kernel on the side stream)
+    assert out["nothing carried"][3] > out["own launches"][3]
+    for a, b in zip(out["nothing carried"][4][:2], out["own launches"][4][:2]):
         assert np.isfinite(a).all() and np.abs(a - b).max() < 2e-4
     assert np.isfinite(out["geometry in the pair launch"][0]).all()
 
