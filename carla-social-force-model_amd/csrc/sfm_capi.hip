@@ -52,7 +52,7 @@ using namespace sfm;
 
 static thread_local std::string g_create_error;
 
-constexpr int GEO_SLICES_MAX = 8;
+constexpr int GEO_SLICES_MAX = 16;
 
 struct DevGeo {
     int* off = nullptr;
@@ -194,6 +194,7 @@ struct SfmHandle {
     uint32_t* work2 = nullptr;
     size_t work2_cap = 0;
     bool begin_done = false, begin_forked = false, last_split = false;
+    int begin_geo_slices = 0;              // > 0: sfm_tick_begin put the geometry workgroups into its pair launch, in this many slices per tile
     uint32_t begin_flags = 0;
     int split_mode = -1;                   // SFM_SPLIT=0: sfm_tick_begin never does anything (A/B, tests)
     int timed_ticks = 0, timed_launches = 0;
@@ -1075,6 +1076,14 @@ static int run_fused(SfmHandle* h, int ticks, uint32_t flags, bool carry) {
     return SFM_OK;
 }
 
+// geometry workgroups inside a pair launch are 4 waves each: as many per tile as give the waves the geometry kernel would use
+// (`slices` x 16), one per tile from 1024 tiles on (where they are spread over the grid)
+static int merged_geo_slices(int tiles, int slices) {
+    static const int ov = getenv("SFM_PG_SLICES") ? atoi(getenv("SFM_PG_SLICES")) : 0;      // A/B only
+    if (ov > 0) return std::min(GEO_SLICES_MAX, ov);
+    return tiles >= 1024 ? 1 : std::min(GEO_SLICES_MAX, 4 * slices);
+}
+
 static int run_ticks(SfmHandle* h, int ticks, uint32_t flags, int phase = PHASE_FULL) {
     int rc = bind(h);
     if (rc) return rc;
@@ -1135,8 +1144,12 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags, int phase = PHASE_
                                       t_lo, t_hi));
         const bool ahead = h->geo_ahead && a.geo;
         h->geo_ahead = false;
-        h->begin_forked = a.geo != nullptr;
-        if (a.geo && !ahead) {
+        // the border / obstacle forces only need the own rows: their workgroups go into the launch of the own-own pairs
+        // (sfm_pair_geo_kernel), or -- SFM_PAIR_GEO=0 -- the geometry kernel runs on the side stream
+        const bool merged = a.geo && !ahead && a.en_ped && h->pair_geo_mode != 0 && h->debug_steps < 0 && !h->geo_stamps;
+        h->begin_forked = a.geo != nullptr && !merged;
+        h->begin_geo_slices = 0;
+        if (a.geo && !ahead && !merged) {
             HIP_TRY(h, hipEventRecord(h->ev_fork, h->stream));
             HIP_TRY(h, hipStreamWaitEvent(h->aux, h->ev_fork, 0));
             HIP_TRY(h, launch_geometry(h->rad, a, h->aux));
@@ -1146,10 +1159,16 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags, int phase = PHASE_
         sa.work = h->work2;
         sa.work_count = h->work_count + 1;
         HIP_TRY(h, launch_sym_list(a, sa, h->stream, LIST_OWN, h->count_zeroed));
-        HIP_TRY(h, launch_sym_pair(h->rad, a, sa, h->stream));
+        if (merged) {
+            a.geo_slices = merged_geo_slices(t_hi - t_lo, a.geo_slices);
+            h->begin_geo_slices = a.geo_slices;
+            HIP_TRY(h, launch_sym_pair_geo(h->rad, a, sa, h->stream));
+        } else {
+            HIP_TRY(h, launch_sym_pair(h->rad, a, sa, h->stream));
+        }
         h->begin_done = true;
         h->begin_flags = flags;
-        h->timed_launches = 3 + (a.geo && !ahead ? 1 : 0);
+        h->timed_launches = 3 + (a.geo && !ahead && !merged ? 1 : 0);
         return SFM_OK;
     }
     const bool finishing = phase == PHASE_END && h->begin_done;   // the own-own pairs of this tick are already in the slab
@@ -1204,14 +1223,22 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags, int phase = PHASE_
         // Mid-sized crowd: four 4-wave workgroups per tile, first in the grid -- c3 41.5 -> 35.1 us.  Large crowd (two-level list):
         // one 4-wave workgroup per tile, spread evenly over the grid -- c5 792 us with the geometry kernel on the side stream,
         // 778 us this way (812 us with 8 192 of them in front of the pair workgroups: they hold every slot for four rounds).
-        const bool geo_in_pair = !ahead && a.geo && n_local > 0 && sym && whole && carried && h->count_zeroed && list_cut && !finishing &&
-                                 a.en_ped && h->N > 1 && h->debug_steps < 0 && !h->stamps && !h->geo_stamps && h->pair_geo_mode != 0;
+        // A whole crowd below the list cutoff (no list, the pair kernel's 2-D grid) gets the same arrangement on every tick, the
+        // geometry workgroups first in the grid with as many waves per tile as the geometry kernel would use: all forces at
+        // N = 512 / 2048 / 4096: 38.9 / 37.9 / 43.6 us with the geometry kernel on the side stream (round 1's default), 19.3 / 22.2 /
+        // 31.0 us with it in line on the main stream, 14.0 / 16.4 / 26.7 us in the pair kernel's launch (tools/mid_crowd_probe.py).
+        const bool plain_grid = !a.tile_box && !lite;                  // no cutoff of any kind: the pair kernel runs its 2-D grid
+        const bool geo_in_pair = !ahead && a.geo && n_local > 0 && sym && !finishing && a.en_ped && h->N > 1 && h->debug_steps < 0 &&
+                                 !h->stamps && !h->geo_stamps && h->pair_geo_mode != 0 && (list_cut || plain_grid);
+        // the geometry kernel on the side stream: shards (beside the exchange and the list), and large whole crowds whose boxes are
+        // not carried; a mid-sized whole crowd keeps it in line -- two streams cost it a factor of two (numbers above)
         const bool fork = !geo_in_pair && a.geo && n_local > 0 && sym &&
-                          ((h->overlap_geo && (!(a.tile_box_out && !lite) || fork_carried)) || finishing);
+                          ((h->overlap_geo && (!whole || (fork_carried && !lite))) || finishing);
         bool list_in_geo = false;
-        static const int pg_slices = getenv("SFM_PG_SLICES") ? atoi(getenv("SFM_PG_SLICES")) : 0;      // A/B only
-        if (geo_in_pair) a.geo_slices = pg_slices > 0 ? pg_slices : (h->n_t >= 1024 ? 1 : 4);
-        if (geo_in_pair) {
+        if (geo_in_pair) a.geo_slices = merged_geo_slices((h->i_end + WAVE - 1) / WAVE - h->i_begin / WAVE, a.geo_slices);
+        if (finishing && h->begin_geo_slices > 0) a.geo_slices = h->begin_geo_slices;      // sfm_tick_begin's pair launch held the geometry workgroups
+        const bool begun_merged = finishing && h->begin_geo_slices > 0;       // the geometry forces of this tick are already there
+        if (geo_in_pair || begun_merged) {
         } else if (ahead) {
         } else if (fork) {
             HIP_TRY(h, hipEventRecord(h->ev_fork, h->stream));
@@ -1251,7 +1278,7 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags, int phase = PHASE_
             }
             if (geo_in_pair) HIP_TRY(h, launch_sym_pair_geo(h->rad, a, sa, h->stream));
             else HIP_TRY(h, launch_sym_pair(h->rad, a, sa, h->stream));
-            if (fork) HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
+            if (fork && !begun_merged) HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
             SymArgs se = sa;
             if (shard_zero) se.zero_count = 2;
             HIP_TRY(h, launch_sym_epilogue(h->rad, a, se, h->stream));
@@ -1263,7 +1290,8 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags, int phase = PHASE_
         }
         h->cur ^= 1;
         // a shard's next geometry forces only need its own new rows: start them now, beside the exchange the caller issues next
-        if (sym && fork && !whole && (flags & SFM_TICK_INTEGRATE) && !h->fsm_on && h->geo_ahead_mode != 0 && t + 1 == ticks &&
+        //  (not when the geometry workgroups ride in the pair launches: then the next sfm_tick_begin / sfm_tick hosts them)
+        if (sym && fork && !begun_merged && !whole && (flags & SFM_TICK_INTEGRATE) && !h->fsm_on && h->geo_ahead_mode != 0 && t + 1 == ticks &&
             !(flags & SFM_TICK_RECORD_FORCES)) {
             TickArgs nx;
             fill_args(h, nx, flags);

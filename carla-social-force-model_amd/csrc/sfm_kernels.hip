@@ -1491,7 +1491,7 @@ __global__ __launch_bounds__(BLOCK) void sfm_pair_sym_kernel(const float4* __res
 // are VALU work -- side by side on the CUs they overlap, which two launches on two streams do not at this size.
 // The geometry part runs as 4-wave workgroups, geo_slices of them per tile (the same 16 waves per tile as sfm_geometry_kernel),
 // so that both kinds share the block size; they come first in the grid and are therefore dispatched first.
-template <bool RAD>
+template <bool RAD, bool CUT>
 __global__ __launch_bounds__(BLOCK) void sfm_pair_geo_kernel(const TickArgs a, const SymArgs sa, int geo_tiles, int geo_stride) {
     constexpr size_t LDS = sizeof(GeoShared<WAVES_PER_BLOCK>) > sizeof(PairShared) ? sizeof(GeoShared<WAVES_PER_BLOCK>) : sizeof(PairShared);
     __shared__ __attribute__((aligned(16))) char smem[LDS];
@@ -1506,8 +1506,9 @@ __global__ __launch_bounds__(BLOCK) void sfm_pair_geo_kernel(const TickArgs a, c
         geometry_block<RAD, WAVES_PER_BLOCK>(a, *reinterpret_cast<GeoShared<WAVES_PER_BLOCK>*>(smem), g % geo_tiles, g / geo_tiles, a.geo_slices,
                                              geo_tiles, (int)threadIdx.x);
     } else {
-        pair_block<RAD, true>(a.pk_cur, a.radius, a.ped, sa, *reinterpret_cast<PairShared*>(smem), bid - min(n_geo, g + 1), 0,
-                              (int)gridDim.x - n_geo, (int)threadIdx.x);
+        const int pb = bid - min(n_geo, g + 1);   // index among the pair workgroups: a run of the list, or (bx, shift) of the 2-D grid
+        if (sa.work) pair_block<RAD, CUT>(a.pk_cur, a.radius, a.ped, sa, *reinterpret_cast<PairShared*>(smem), pb, 0, (int)gridDim.x - n_geo, (int)threadIdx.x);
+        else pair_block<RAD, CUT>(a.pk_cur, a.radius, a.ped, sa, *reinterpret_cast<PairShared*>(smem), pb % sa.n_t, pb / sa.n_t, sa.n_t, (int)threadIdx.x);
     }
 }
 
@@ -2292,14 +2293,18 @@ hipError_t launch_sym_pair(bool rad, const TickArgs& a, const SymArgs& sa, hipSt
 hipError_t launch_sym_pair_geo(bool rad, const TickArgs& a, const SymArgs& sa, hipStream_t st) {
     const int tiles = ((a.i_end + WAVE - 1) >> 6) - (a.i_begin >> 6);
     const int rounds = std::min(16, std::max(2, sa.n_t / 64));
-    const int n_geo = tiles * a.geo_slices, n_pair = 256 * 8 * rounds;
+    const int n_geo = tiles * a.geo_slices, n_pair = sa.work ? 256 * 8 * rounds : sa.n_t * (sa.n_t / 2 + 1);
     const dim3 grid(n_geo + n_pair);
     // more geometry workgroups than the CUs hold in one round beside the pair workgroups: spread them evenly over the grid
     static const int stride_ov = getenv("SFM_PG_STRIDE") ? atoi(getenv("SFM_PG_STRIDE")) : 0;      // A/B only
     int stride = n_geo > 256 * 4 ? std::max(1, (n_geo + n_pair) / n_geo) : 1;
     if (stride_ov > 0) stride = std::min(stride_ov, std::max(1, (n_geo + n_pair) / n_geo));
-    if (rad) hipLaunchKernelGGL((sfm_pair_geo_kernel<true>), grid, dim3(BLOCK), 0, st, a, sa, tiles, stride);
-    else hipLaunchKernelGGL((sfm_pair_geo_kernel<false>), grid, dim3(BLOCK), 0, st, a, sa, tiles, stride);
+    if (stride > 1 && !(stride & 1)) --stride;      // odd: workgroup w runs on CU w mod 256, an even stride would put every geometry workgroup on a few CUs
+    const bool cut = sa.vmax != nullptr;           // as launch_sym_pair: list (or lite) cutoff -> the per-step tests are on
+    if (rad) { if (cut) hipLaunchKernelGGL((sfm_pair_geo_kernel<true, true>), grid, dim3(BLOCK), 0, st, a, sa, tiles, stride);
+               else hipLaunchKernelGGL((sfm_pair_geo_kernel<true, false>), grid, dim3(BLOCK), 0, st, a, sa, tiles, stride); }
+    else { if (cut) hipLaunchKernelGGL((sfm_pair_geo_kernel<false, true>), grid, dim3(BLOCK), 0, st, a, sa, tiles, stride);
+           else hipLaunchKernelGGL((sfm_pair_geo_kernel<false, false>), grid, dim3(BLOCK), 0, st, a, sa, tiles, stride); }
     return hipGetLastError();
 }
 
