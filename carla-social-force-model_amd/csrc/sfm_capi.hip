@@ -1076,12 +1076,15 @@ static int run_fused(SfmHandle* h, int ticks, uint32_t flags, bool carry) {
     return SFM_OK;
 }
 
-// geometry workgroups inside a pair launch are 4 waves each: as many per tile as give the waves the geometry kernel would use
-// (`slices` x 16), one per tile from 1024 tiles on (where they are spread over the grid)
+// geometry workgroups inside a pair launch are 4 waves each; per tile: 16 of them up to 32 tiles, 8 up to 63, 4 up to 1023, one
+// from 1024 tiles on (where they are spread over the grid).  Measured, all forces (tools/mid_crowd_probe.py, c3): N = 512: 16.6 /
+// 14.3 / 14.0 us per tick at 4 / 8 / 16; N = 2048: 21.0 / 16.4 / 16.4; N = 4096: 27.7 / 23.2 / 24.8 / 26.7 at 2 / 4 / 8 / 16;
+// c3 (256 tiles): 47.3 / 35.2 / 34.9 / 44 at 1 / 2 / 4 / 8; c5: 777 / 781 / 797 at 1 / 2 / 4.
 static int merged_geo_slices(int tiles, int slices) {
     static const int ov = getenv("SFM_PG_SLICES") ? atoi(getenv("SFM_PG_SLICES")) : 0;      // A/B only
+    (void)slices;
     if (ov > 0) return std::min(GEO_SLICES_MAX, ov);
-    return tiles >= 1024 ? 1 : std::min(GEO_SLICES_MAX, 4 * slices);
+    return tiles >= 1024 ? 1 : tiles >= 64 ? 4 : tiles > 32 ? 8 : 16;
 }
 
 static int run_ticks(SfmHandle* h, int ticks, uint32_t flags, int phase = PHASE_FULL) {
@@ -1226,7 +1229,7 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags, int phase = PHASE_
         // A whole crowd below the list cutoff (no list, the pair kernel's 2-D grid) gets the same arrangement on every tick, the
         // geometry workgroups first in the grid with as many waves per tile as the geometry kernel would use: all forces at
         // N = 512 / 2048 / 4096: 38.9 / 37.9 / 43.6 us with the geometry kernel on the side stream (round 1's default), 19.3 / 22.2 /
-        // 31.0 us with it in line on the main stream, 14.0 / 16.4 / 26.7 us in the pair kernel's launch (tools/mid_crowd_probe.py).
+        // 31.0 us with it in line on the main stream, 13.9 / 16.3 / 23.2 us in the pair kernel's launch (tools/mid_crowd_probe.py).
         const bool plain_grid = !a.tile_box && !lite;                  // no cutoff of any kind: the pair kernel runs its 2-D grid
         const bool geo_in_pair = !ahead && a.geo && n_local > 0 && sym && !finishing && a.en_ped && h->N > 1 && h->debug_steps < 0 &&
                                  !h->stamps && !h->geo_stamps && h->pair_geo_mode != 0 && (list_cut || plain_grid);
