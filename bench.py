@@ -194,6 +194,12 @@ def main():
     ap.add_argument("--no-single-ref", action="store_true", help="G > 1: skip the one-GPU run of the same workload")
     ap.add_argument("--cpu-budget", type=float, default=10.0)
     args = ap.parse_args()
+    # stdout carries exactly ONE line, the JSON record: libraries that print at start-up (RCCL: "Librccl path ...", gloo's rank
+    # banner in rehearsals) write to file descriptor 1 from C, so it is pointed at stderr for the run and the record goes to a
+    # duplicate of the original
+    sys.stdout.flush()
+    record_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
@@ -373,7 +379,7 @@ def main():
             out["single_gpu_same_workload"] = single_ref
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sc, forces, cfg, args.cpu_budget)
-        print(json.dumps(out), flush=True)
+        os.write(record_fd, (json.dumps(out) + "\n").encode())
     eng.close()
     if world > 1:
         dist.destroy_process_group()
