@@ -201,6 +201,7 @@ def main():
     record_fd = os.dup(1)
     os.dup2(2, 1)
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on these hosts (RCCL between processes); before HIP comes up
     import torch
     import torch.distributed as dist
     from carla_social_force_model_amd import scenarios
