@@ -10,7 +10,7 @@ Metric: SFM ticks/s (BASELINE.json "SFM ticks/s and ns/pedestrian-pair"); ns/pai
 
 Timing protocol.  After W untimed warm-up steps a WINDOW is exactly K steps bracketed by a
 barrier + torch.cuda.synchronize() on both sides, its duration the MAX over ranks.  At least 5 windows are run, and
-more until they add up to >= 1 s (--min-seconds); `value` = K / the MEDIAN window; `windows`, `min`, `max` and the
+more until they add up to >= 3 s (--min-seconds); `value` = K / the MEDIAN window; `windows`, `min`, `max` and the
 mean over all windows are on the line.  `steps` / `warmup` echo the arguments.
 
 Workloads (--workload overrides the default, and the SAME workload can be run at every G):
@@ -26,7 +26,8 @@ Workloads (--workload overrides the default, and the SAME 
 
 Roofline record.  The dominant kernel is the pedestrian-pair kernel.  Its binding resource is VALU issue (DESIGN.md
 3.6): `roofline.bound = "valu_issue"`, achieved = VALU wave-instructions per launch (SQ_INSTS_VALU, mean per launch from
-the rocprofv3 --pmc passes summarised in profiles/r02_pmc_summary.csv, a tracked file) / the kernel's own launch
+the rocprofv3 --pmc passes summarised in profiles/r03_pmc_summary.csv, a tracked file whose header carries the git blob id of
+sfm_kernels.hip at collection time: `roofline.counters_stale` says whether the loaded build differs) / the kernel's own launch
 duration measured live with HIP events on the launch stream, against 1024 SIMDs x 0.5 wave-instr/clk x 2.4 GHz.
 `roofline.hbm_algorithmic` keeps SURVEY.md 8d's yardstick (16 B per ordered pair / launch time against 8 TB/s) and
 `roofline.traffic` the HBM bytes per launch from the FETCH_SIZE / WRITE_SIZE passes (same file).
@@ -47,7 +48,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak
 SIMDS, CLOCK_HZ = 1024, 2.4e9
 VALU_PEAK_GINSTR = SIMDS * 0.5 * CLOCK_HZ / 1e9     # v_fma_f32 (wave64): 2 cycles per SIMD (MI355X_MICROARCH.md, cycle constants)
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc_summary.csv")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03_pmc_summary.csv")
+KERNEL_SOURCE = os.path.join(ROOT, "carla-social-force-model_amd", "csrc", "sfm_kernels.hip")   # beside the loaded libsfm_hip.so
 # The counter passes (tools/pmc_run.sh -> tools/pmc_ticks.py) run this many ticks from the uploaded scenario.  With a cutoff the
 # pair kernel's instruction count depends on where the crowd has got to, so the launch duration that goes with those
 # counters is measured at the same point (a second handle, same ticks), not at the end of the timed run.
@@ -156,17 +158,36 @@ def cpu_baseline(sc, forces, cfg, budget_s=15.0):
     return out
 
 
+def git_blob_sha1(path):
+    """The git blob id of a file's content (sha1 of "blob <size>\\0" + bytes): what `git hash-object` prints, computed here
+    because the GPU box has no .git directory."""
+    import hashlib
+    try:
+        data = open(path, "rb").read()
+    except OSError:
+        return None
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+
+
 def pmc_counters(workload, kernel):
-    """Mean per-launch counter values of `kernel` on `workload` from the tracked PMC summary (tools/pmc_summarize.py)."""
-    out = {}
+    """Mean per-launch counter values of `kernel` on `workload` from the tracked PMC summary (tools/pmc_summarize.py), and
+    whether that summary was collected on another version of the kernels than the one next to the loaded library: its
+    header comment carries the git blob id of sfm_kernels.hip at collection time (`counters_stale`)."""
+    out, blob = {}, None
     try:
         with open(PMC_SUMMARY) as f:
-            for row in csv.DictReader(f):
-                if row["workload"] == workload and row["kernel"] == kernel:
-                    out[row["counter"]] = float(row["mean_per_launch"])
+            lines = f.readlines()
+        for ln in lines:
+            if ln.startswith("#") and "sfm_kernels.hip" in ln and "git-blob" in ln:
+                blob = ln.split("git-blob")[1].split()[0]
+        for row in csv.DictReader(ln for ln in lines if not ln.startswith("#")):
+            if row["workload"] == workload and row["kernel"] == kernel:
+                out[row["counter"]] = float(row["mean_per_launch"])
     except OSError:
         pass
-    return out
+    here = git_blob_sha1(KERNEL_SOURCE)
+    stale = None if (blob is None or here is None) else (blob != here)
+    return out, {"counters_kernel_source_blob": blob, "loaded_kernel_source_blob": here, "counters_stale": stale}
 
 
 def timed_windows(step, barrier, reduce_max, steps, min_windows, min_seconds, max_windows=5000):
@@ -189,7 +210,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--workload", default="auto", choices=["auto", "c1", "c2", "c3", "c4", "c5"])
     ap.add_argument("--windows", type=int, default=5, help="minimum number of timed windows of --steps steps")
-    ap.add_argument("--min-seconds", type=float, default=1.0, help="keep adding windows until they total this long")
+    ap.add_argument("--min-seconds", type=float, default=3.0, help="keep adding windows until they total this long (SURVEY.md 8d: >= 3 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-ref", action="store_true", help="G > 1: skip the one-GPU run of the same workload")
     ap.add_argument("--cpu-budget", type=float, default=10.0)
@@ -280,7 +301,8 @@ def main():
     # whole tick on the launch stream (HIP events, no collective in between) ...
     eng.engine.set_timing(True)
     reps = min(max(args.steps, 1), 200 if sc.n <= 16384 else 10)
-    eng.engine.run(reps, redraw=True)
+    # (a rank of a sharded run gets no exchange here: one tick only, so that the other ranks' rows it reads are one tick old at most)
+    eng.engine.run(reps if world == 1 else 1, redraw=True)
     ev_ms, ev_ticks, ev_launches = eng.engine.timing()
     tick_us = ev_ms * 1e3 / max(ev_ticks, 1)
     variant = eng.engine.kernel_variant()
@@ -311,36 +333,60 @@ def main():
     alg_tick = algorithmic_bytes(sc, forces, hi - lo)
     alg_gbs = alg / (kernel_us * 1e-6) / 1e9
     # counters of this kernel on this workload (whole crowd on one GPU), mean per launch, from the tracked summary
-    pmc = pmc_counters(name, dominant) if world == 1 else {}
+    pmc, stamp = pmc_counters(name, dominant)
+    src = os.path.relpath(PMC_SUMMARY, ROOT)
     traffic = None
-    if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:   # KiB; FETCH_SIZE doubled for 16-B/lane reads on gfx950 (MI355X_MICROARCH.md, HBM)
+    if world == 1 and "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:   # KiB; FETCH_SIZE doubled for 16-B/lane reads on gfx950 (MI355X_MICROARCH.md, HBM)
         traffic = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
     hbm_alg = {"bound": "hbm", "achieved": alg_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_gbs / HBM_PEAK_GBS,
                "algorithmic_bytes_per_launch": alg, "traffic_over_algorithmic": (traffic / alg) if (traffic and alg) else None,
                "note": "SURVEY.md 8d yardstick: 16 B per ORDERED pair x the pairs one launch covers / its launch time. The operand "
                        "stream is served from registers / L2, so this exceeds the HBM peak as soon as the kernel is fast: it does "
                        "not bind (traffic_over_algorithmic says how little of it reaches HBM)"}
-    if "SQ_INSTS_VALU" in pmc:
+    peak_def = "1024 SIMDs x 0.5 wave64 VALU instr/clk (v_fma_f32 = 2 cycles) x 2.4 GHz"
+    if world == 1 and "SQ_INSTS_VALU" in pmc:
         insts = pmc["SQ_INSTS_VALU"]
         ach = insts / (kernel_us * 1e-6) / 1e9
         roof = {"bound": "valu_issue", "achieved": ach, "peak": VALU_PEAK_GINSTR, "unit": "G wave-instr/s",
                 "frac": ach / VALU_PEAK_GINSTR, "traffic": traffic,
                 "valu_wave_instructions_per_launch": insts,
-                "counters": {k: pmc[k] for k in sorted(pmc)}, "counters_source": "profiles/r02_pmc_summary.csv",
-                "peak_definition": "1024 SIMDs x 0.5 wave64 VALU instr/clk (v_fma_f32 = 2 cycles) x 2.4 GHz"}
+                "counters": {k: pmc[k] for k in sorted(pmc)}, "counters_source": src, "peak_definition": peak_def}
         if pair_terms:
             roof["valu_instructions_per_64_pair_step"] = insts / (pair_terms / 64.0)
         if "SQ_WAIT_INST_ANY" in pmc and "SQ_WAVE_CYCLES" in pmc and pmc["SQ_WAVE_CYCLES"] > 0:
             roof["wait_inst_any_over_wave_cycles"] = pmc["SQ_WAIT_INST_ANY"] / pmc["SQ_WAVE_CYCLES"]
+        if sc.n < 256:
+            # a crowd of one tile: two dependent launches of a handful of workgroups.  Nothing on the chip is busy; what the tick
+            # costs is its chain of launches and memory round trips, and a VALU fraction of it says nothing
+            launches = ev_launches / max(ev_ticks, 1)
+            floor_us = launches * 1.45               # MI355X_MICROARCH.md price list, row "boundary": a dependent trivial launch
+            roof.update({"bound": "latency", "valu_issue_frac": roof["frac"], "achieved": tick_us, "peak": floor_us, "unit": "us per tick",
+                         "frac": floor_us / tick_us,
+                         "peak_definition": "dependent kernel launches per tick x 1.45 us (the guide's kernel-boundary price); frac = that floor / the measured tick",
+                         "dependent_chain": f"{launches:.2f} launches per tick; geometry: kernel start -> tile rows -> polyline records -> points -> "
+                                            "LDS combine -> store; tick kernel: state -> geometry sums -> integrate -> store"})
+    elif world > 1 and pair_terms and "VALU_PER_64_PAIR_STEP" in pmc:
+        # a rank of a sharded run: no counter pass of its own.  Its VALU work is the Moussaid terms its pair kernel evaluated in the
+        # last tick (sfm_get_pair_work: a count kept by the library) x the instructions per 64-term step the committed
+        # whole-crowd counter passes measured for this kernel on this workload
+        insts = pair_terms / 64.0 * pmc["VALU_PER_64_PAIR_STEP"]
+        ach = insts / (kernel_us * 1e-6) / 1e9
+        roof = {"bound": "valu_issue", "achieved": ach, "peak": VALU_PEAK_GINSTR, "unit": "G wave-instr/s", "frac": ach / VALU_PEAK_GINSTR,
+                "traffic": None, "valu_wave_instructions_per_launch": insts, "counters_source": src, "peak_definition": peak_def,
+                "note": "rank 0 of a sharded run: instructions = its evaluated pair terms / 64 x VALU_PER_64_PAIR_STEP of the whole-crowd "
+                        "counter passes (no PMC pass is run per rank); kernel_us is this rank's pair kernel alone"}
     else:                                              # no counter pass committed for this workload / rank layout
-        roof = dict(hbm_alg)
-        roof["traffic"] = traffic
-        roof["note"] = "no PMC summary for this workload in profiles/r02_pmc_summary.csv: only the algorithmic-bytes yardstick; " + roof["note"]
+        roof = {"bound": "valu_issue", "achieved": None, "peak": VALU_PEAK_GINSTR, "unit": "G wave-instr/s", "frac": None, "traffic": None,
+                "peak_definition": peak_def,
+                "note": f"no committed counter pass for {dominant} on {name} in {src}: the fraction is not derivable here; "
+                        "hbm_algorithmic below is SURVEY.md 8d's yardstick, which does not bind"}
+    roof.update(stamp)
+    if roof.get("frac") is not None and roof["bound"] == "valu_issue" and roof["frac"] > 1.0:      # never publish a non-physical fraction
+        roof.update({"frac": None, "note": (roof.get("note", "") + " [fraction above 1 withheld: counters do not belong to this build]").strip()})
     roof.update({"kernel": dominant, "kernel_variant": variant, "kernel_us": kernel_us, "kernel_us_state": state_note,
                  "kernel_us_end_of_run": kernel_us_end, "tick_us": tick_us,
                  "launches_per_tick": ev_launches / max(ev_ticks, 1), "algorithmic_bytes_per_tick": alg_tick})
-    if roof.get("bound") == "valu_issue":
-        roof["hbm_algorithmic"] = hbm_alg
+    roof["hbm_algorithmic"] = hbm_alg
     barrier()
 
     if rank == 0:

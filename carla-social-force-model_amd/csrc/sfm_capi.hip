@@ -1341,6 +1341,10 @@ int sfm_profile_dominant_kernel(SfmHandle* h, int reps, float* avg_us) {
         const size_t np_ = (size_t)h->N_pad;
         float4 *pk_keep = nullptr, *own_keep = nullptr;
         uint32_t* draws_keep = nullptr;
+        struct Keep {                                  // freed on every way out (HIP_TRY returns early)
+            float4 *&a, *&b; uint32_t*& c;
+            ~Keep() { if (a) hipFree(a); if (b) hipFree(b); if (c) hipFree(c); }
+        } keep{pk_keep, own_keep, draws_keep};
         HIP_TRY(h, dev_realloc(pk_keep, np_)); HIP_TRY(h, dev_realloc(own_keep, np_)); HIP_TRY(h, dev_realloc(draws_keep, np_));
         HIP_TRY(h, hipMemcpyAsync(pk_keep, h->pk[h->cur], sizeof(float4) * np_, hipMemcpyDeviceToDevice, h->stream));
         HIP_TRY(h, hipMemcpyAsync(own_keep, h->own, sizeof(float4) * np_, hipMemcpyDeviceToDevice, h->stream));
@@ -1363,7 +1367,6 @@ int sfm_profile_dominant_kernel(SfmHandle* h, int reps, float* avg_us) {
         float ms = 0.f;
         HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
         *avg_us = ms * 1000.0f / (float)reps;
-        hipFree(pk_keep); hipFree(own_keep); hipFree(draws_keep);
         h->carry_ok = false;
         h->timing_valid = false;
         return SFM_OK;
@@ -1574,22 +1577,30 @@ int sfm_download_draw_counts(SfmHandle* h, uint32_t* counts) {
     return SFM_OK;
 }
 
+// A device pointer handed out: the caller may write the rows through it, so nothing derived from the stored state survives --
+// the fused tick's partial forces, the tile boxes the last epilogue left for the next tick's list, geometry forces launched ahead.
+static void caller_may_write(SfmHandle* h) {
+    h->carry_ok = false;
+    h->boxes_valid = false;
+    drop_geo_ahead(h);
+}
+
 void* sfm_packed_state_ptr(SfmHandle* h, int* n_pad) {
     if (!h) return nullptr;
-    h->carry_ok = false;                           // the caller may write through the pointer
+    caller_may_write(h);
     if (n_pad) *n_pad = h->N_pad;
     return h->pk[h->cur];
 }
 
 void* sfm_packed_z_ptr(SfmHandle* h) {
     if (!h || !h->z3) return nullptr;
-    h->carry_ok = false;                           // the caller may write through the pointer
+    caller_may_write(h);
     return h->zv[h->cur];
 }
 
 void* sfm_row_data_ptr(SfmHandle* h, int which, int* bytes_per_row) {
     if (!h || which < 0 || which > 1) return nullptr;
-    h->carry_ok = false;                           // the caller may write through the pointer
+    caller_may_write(h);
     if (bytes_per_row) *bytes_per_row = which == 0 ? (int)sizeof(float4) : (int)sizeof(uint32_t);
     return which == 0 ? (void*)h->own : (void*)h->draws;
 }

@@ -50,8 +50,15 @@ def block_layout(world):
 
 
 def equal_bounds(n, n_pad, world):
-    """[b_0 = 0, b_1, ..., b_world = n]: the equal split as a bounds list."""
-    return [shard_bounds(n, n_pad, r, world)[0] for r in range(world)] + [n]
+    """[b_0 = 0, b_1, ..., b_world = n]: the equal split as a bounds list.  Every interior bound is a whole number of 64-row
+    tiles (sfm_set_partition and the symmetric kernel's shards need that) -- the library's own default split,
+    ``n_pad * r / world`` rounded down to a tile -- and never beyond the last whole tile of the real rows.  When
+    ``n_pad / world`` is itself a multiple of 64 (every BASELINE config) this is ``shard_bounds``' split and the exchange is
+    one in-place all-gather; otherwise the shares differ by a tile and the exchange goes through the padded staging buffer."""
+    if n_pad % world:
+        raise ValueError(f"padded size {n_pad} not divisible by world size {world}")
+    top = (n // TILE) * TILE
+    return [min((n_pad * r // world) // TILE * TILE, top) for r in range(world)] + [n]
 
 
 def balanced_bounds(bounds, costs, n, damping=0.7, min_rows=TILE):
@@ -83,8 +90,13 @@ def balanced_bounds(bounds, costs, n, damping=0.7, min_rows=TILE):
         ideal = bounds[r] + frac * rows[r]
         moved = bounds[k] + damping * (ideal - bounds[k])
         b = int(round(moved / TILE)) * TILE
-        b = max(b, new[-1] + min_rows)
-        b = min(b, n - (world - k) * min_rows)
+        # whole tiles, at least ``min_rows`` per rank where the crowd has that many tiles (a crowd of fewer tiles than ranks
+        # leaves some ranks without rows: their bounds coincide, still on tile edges)
+        step = max(TILE, (min_rows + TILE - 1) // TILE * TILE)
+        b = max(b, new[-1] + step)
+        top = (n // TILE) * TILE                 # the last rank can live on the partial tile [top, n) if there is one
+        b = min(b, top - (world - 1 - k) * step - (0 if n > top else step))
+        b = max(b, new[-1])
         new.append(b)
     new.append(n)
     return new

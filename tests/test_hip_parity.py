@@ -722,6 +722,95 @@ def test_fused_tick_matches_the_two_kernel_tick(n, use_radius, coincide, monkeyp
     assert np.array_equal(wp[same], wp0[same])
 
 
+def _fused_resync_rounds(eng, sc, prm, n_ticks, row_blocks, seed, world_side, thr=2.0):
+    """K calls of ``eng.run(1, redraw=True)`` on a handle whose state was just uploaded / downloaded: every call is the launch in
+    front (pairs of the stored state) + ONE integrating launch of sfm_fused_tick_kernel, i.e. the kernel's own prologue turns the
+    partial forces into v', x' and the next waypoint.  After every call the downloaded v', x', waypoints and draw counters are
+    compared with the oracle stepping from the device's PREVIOUS fp32 state (pedestrian_simulation.py:81-83,117-124;
+    forces.py:46-117): v' through P.check_velocity at 1e-5 (with the oracle's discontinuity exposure), x' to 1e-6."""
+    n = sc.n
+    loc, vel, wp = sc.loc.copy(), sc.vel.copy(), sc.waypoint.copy()
+    draws = np.zeros(n, dtype=np.int64)
+    crossing = np.zeros(n, bool)
+    worst_v = worst_x = 0.0
+    for k in range(n_ticks):
+        eng.run(1, redraw=True)
+        variant = eng.kernel_variant()
+        assert "fused" in variant, variant
+        dloc, dvel, dwp = eng.state()
+        ddraws = eng.draw_counts().astype(np.int64)
+        assert np.isfinite(dloc).all() and np.isfinite(dvel).all(), f"tick {k}"
+        for r in row_blocks:
+            with np.errstate(all="ignore"):
+                _, _, v_new, expo, _ = c_oracle.tick(loc, vel, wp, sc.target_speed, sc.radius, crossing, O.Geometry(), prm, 0.05,
+                                                     rows=r, theta_tol=P.THETA_TOL)
+            sl = slice(r[0], r[1])
+            worst_v = max(worst_v, P.check_velocity(dvel[sl], v_new, expo, 0.05))
+            x_new = loc[sl] + 0.05 * v_new
+            x_new[:, 2] = loc[sl, 2]
+            # a pedestrian within fp32 noise of a discontinuity moves by dt * dt * exposure at most
+            allow = 1e-6 * np.maximum(1.0, np.abs(x_new).max(axis=1)) + 0.05 * 0.05 * expo * 1.001
+            err = np.abs(dloc[sl] - x_new).max(axis=1)
+            assert (err <= allow).all(), f"tick {k}: x' off by {err.max():.3g}"
+            worst_x = max(worst_x, float((err / np.maximum(1.0, np.abs(x_new).max(axis=1))).max()))
+            # arrival on the pre-move position (run_simulation.py:118), next waypoint from the counter-based stream
+            dist = np.linalg.norm(wp[sl, :2] - loc[sl, :2], axis=1)
+            sure = np.abs(dist - thr) > 1e-4
+            hit = dist < thr
+            want_draws = draws[sl] + hit
+            assert np.array_equal(ddraws[sl][sure], want_draws[sure]), f"draw counters at tick {k}"
+            want_wp = wp[sl, :2].copy()
+            ids = np.nonzero(hit)[0]
+            if ids.size:
+                want_wp[ids] = O.redraw_waypoint(ids + r[0], want_draws[ids], seed, world_side)
+            assert np.allclose(dwp[sl][sure], want_wp[sure], rtol=0, atol=1e-4), f"waypoints at tick {k}"
+        loc, vel = dloc, dvel                                   # carry on from the device's fp32 state
+        wp = np.concatenate([dwp, np.zeros((n, 1))], axis=1)
+        draws = ddraws
+    return variant, worst_v, worst_x, int(draws.sum())
+
+
+@pytest.mark.parametrize("n,use_radius,coincide", [(256, False, False), (300, True, False), (1000, False, True), (4160, False, False)])
+def test_fused_tick_pinned_to_the_oracle(n, use_radius, coincide):
+    """sfm_fused_tick_kernel -- the kernel bench.py times on c2 -- against the ORACLE directly, re-synchronised every tick
+    (round-2 verdict item 1): whole and ragged tiles, odd group counts, use_ped_radius, a coincident pair (NaN in the fast body,
+    recomputed with the exact one), with waypoint redraws.  Tolerances: v' 1e-5 relative per pedestrian, x' 1e-6."""
+    sc = scenarios.make_scenario(n, 8800 + n, density=0.25 if use_radius else 1.0)
+    if coincide:
+        sc.loc[n // 2] = sc.loc[n // 2 + 70]                  # two pedestrians of different tiles at the same place
+        sc.loc[5] = sc.loc[6]                                 # ... and two of the same tile (different velocities: finite)
+    cfg = default_sfm_config(("acceleration_force", "pedestrian_force"))
+    cfg["use_ped_radius"] = use_radius
+    prm = O.OracleParams.from_config(cfg)
+    side = 0.3 * sc.world_side                                # a small waypoint square: arrivals inside 8 ticks
+    eng = SfmEngine(cfg, 0.05)
+    try:
+        eng.upload_state(sc.loc, sc.vel, sc.waypoint, sc.target_speed, sc.radius, None)
+        eng.set_waypoint_stream(sc.seed, side, 2.0)
+        variant, wv, wx, nd = _fused_resync_rounds(eng, sc, prm, 8, ((0, n),), sc.seed, side)
+        print(f"\nfused tick vs oracle, N={n}: {variant}  worst v' rel {wv:.3g}  worst x' rel {wx:.3g}  redraws {nd}")
+    finally:
+        eng.close()
+
+
+def test_fused_tick_pinned_to_the_oracle_at_c2():
+    """The same at BASELINE config 2 exactly as bench.py runs it (N = 4096, acceleration + pedestrian force), three 128-row blocks
+    of the caller's order per tick, 8 ticks, each produced by sfm_fused_tick_kernel."""
+    sc, forces = scenarios.baseline_scenario("c2")
+    cfg = default_sfm_config(forces)
+    prm = O.OracleParams.from_config(cfg)
+    n = sc.n
+    blocks = ((0, 128), (n // 2 - 64, n // 2 + 64), (n - 128, n))
+    eng = SfmEngine(cfg, 0.05)
+    try:
+        eng.upload_state(sc.loc, sc.vel, sc.waypoint, sc.target_speed, sc.radius, None)
+        eng.set_waypoint_stream(sc.seed, sc.world_side, 2.0)
+        variant, wv, wx, nd = _fused_resync_rounds(eng, sc, prm, 8, blocks, sc.seed, sc.world_side)
+        print(f"\nfused tick vs oracle at c2: {variant}  worst v' rel {wv:.3g}  worst x' rel {wx:.3g}  redraws {nd}")
+    finally:
+        eng.close()
+
+
 @pytest.mark.parametrize("waves,blocked", [("8", "1"), ("16", "0")])
 def test_fused_tick_variants_and_pedestrian_force_alone(waves, blocked, monkeypatch):
     """The fused tick's A/B variants (8-wave workgroups; the plain order of the work items where the XCD-aware one applies) and a

@@ -190,6 +190,31 @@ def test_balanced_bounds_evens_out_a_lopsided_cost():
     assert balanced_bounds([0, 256], [5.0], 256) == [0, 256]
 
 
+def test_interior_shard_bounds_are_whole_tiles_for_any_size():
+    """sfm_set_partition (and the symmetric kernel's shards) only take interior bounds that are multiples of 64: the equal
+    split and every re-balanced split must deliver that for odd crowd sizes and world sizes too (round-2 advisor finding:
+    n = 520 on 4 ranks used to give [0, 192, 384, 520, 520], n_pad = 768 on 8 ranks 96-row chunks)."""
+    from carla_social_force_model_amd.stepper import balanced_bounds, equal_bounds
+    rng = np.random.default_rng(5)
+    for n in (1, 63, 64, 200, 520, 700, 768, 1000, 4096, 4160, 10007, 65536):
+        n_pad = (n + 255) // 256 * 256
+        for world in (1, 2, 4, 8):
+            b = equal_bounds(n, n_pad, world)
+            assert len(b) == world + 1 and b[0] == 0 and b[-1] == n
+            assert all(b[k] <= b[k + 1] for k in range(world)), (n, world, b)
+            assert all(x % 64 == 0 for x in b[:-1]), (n, world, b)
+            if (n_pad // world) % 64 == 0 and n == n_pad:
+                assert b == [n_pad // world * r for r in range(world + 1)]       # the in-place all-gather's even split
+            for _ in range(4):
+                costs = [float(c) for c in rng.uniform(0.5, 2.0, world) * np.maximum(1, np.diff(b))]
+                b = balanced_bounds(b, costs, n)
+                assert len(b) == world + 1 and b[0] == 0 and b[-1] == n
+                assert all(b[k] <= b[k + 1] for k in range(world)), (n, world, b)
+                assert all(x % 64 == 0 for x in b[:-1]), (n, world, b)
+    assert equal_bounds(520, 768, 4) == [0, 192, 384, 512, 520]
+    assert balanced_bounds([0, 64, 128, 192, 200], [1.0, 1.0, 1.0, 30.0], 200) == [0, 64, 128, 192, 200]
+
+
 def test_gap_acceptance_and_vehicle_rings_agree_with_the_oracles_restatement():
     """SURVEY.md section 8f rows 2 and 3.  Neither obstacles.py (carla) nor check_traffic.py (shapely) can run here and the
     reference holds no fixtures for them, so the product's host code is checked against an independent float64 restatement in

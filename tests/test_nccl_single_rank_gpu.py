@@ -261,3 +261,51 @@ def test_antipodal_tile_pairs_across_the_shard_boundary_are_evaluated(monkeypatc
         merged = np.where(mine0[:, None], got[0][k], got[1][k])
         assert np.isfinite(merged).all()
         assert np.allclose(merged, ref[k], rtol=2e-5, atol=2e-5)
+
+
+def test_rows_written_through_the_packed_pointer_invalidate_the_carried_tile_boxes():
+    """A whole crowd at N >= 8192 carries the NEXT tick's tile boxes from its epilogue (no sfm_tile_bounds launch).  A caller that
+    writes the packed rows through sfm_packed_state_ptr in between must get a tile-pair list built from fresh boxes (round-2
+    advisor finding: the getters only reset the fused tick's carry): moved crowd through the pointer == fresh upload of it."""
+    import torch
+    from carla_social_force_model_amd.engine import SfmEngine
+    from carla_social_force_model_amd.stepper import HipShardEngine
+
+    n = 8192
+    sc = scenarios.make_scenario(n, 77)
+    cfg = default_sfm_config(("acceleration_force", "pedestrian_force"))
+    eng = HipShardEngine(cfg, 0.05, device=0)
+    other = SfmEngine(cfg, 0.05)
+    try:
+        eng.load(sc)
+        eng.run(3)                                      # the last epilogue left boxes for tick 4
+        (buf, width), = eng.packed()                    # the pointer is handed out: the caller may write
+        rows = buf.view(-1, 4)[:n]
+        moved = rows.clone()
+        far = moved[:, 0] > moved[:, 0].median()        # half the crowd goes 300 m away: every tile's box changes or moves
+        moved[far, 0] += 300.0
+        rows.copy_(moved)
+        eng.synchronize()
+        eng.engine.tick(record=True)
+        assert "sym" in eng.engine.kernel_variant()
+        got_f, got_v = eng.engine.forces("pedestrian_force"), eng.engine.velocities()
+        loc, vel, wp = eng.engine.state()               # (velocities: those the tick left in the state's place are read above)
+        loc0, vel0, wp0 = loc.copy(), vel.copy(), wp.copy()
+        # the same state uploaded afresh (the tick above did not integrate positions; its input velocities are `moved`'s)
+        perm_state = moved.cpu().numpy().astype(np.float64)
+        # rows are in the library's order: map back through positions (unique) to the caller's order
+        key = {tuple(np.float32(p)): i for i, p in enumerate(loc0[:, :2])}
+        vel_in = np.zeros_like(vel0)
+        for r in perm_state:
+            vel_in[key[(np.float32(r[0]), np.float32(r[1]))], :2] = r[2:4]
+        wp3 = np.zeros_like(loc0); wp3[:, :2] = wp0
+        other.upload_state(loc0, vel_in, wp3, sc.target_speed, sc.radius, None)
+        other.tick(record=True)
+        want_f, want_v = other.forces("pedestrian_force"), other.velocities()
+        # another packing order sums in another order: rounding only -- a stale list drops whole tile pairs (errors of order one)
+        scale = np.abs(want_f).max()
+        assert np.abs(got_f - want_f).max() <= 2e-5 * scale, np.abs(got_f - want_f).max() / scale
+        assert np.abs(got_v - want_v).max() <= 1e-5
+    finally:
+        eng.close()
+        other.close()

@@ -4,9 +4,15 @@
 
 Every *_counter_collection.csv below DIR is read (one pass per counter group: SQ counters, FETCH_SIZE, WRITE_SIZE are
 separate runs -- MI355X_MICROARCH.md, rocprofv3 PMC slots); per (kernel, counter) the mean over the dispatches is written,
-skipping each kernel's first `SKIP` dispatches (warm-up).  Kernel names are cut to the bare function name."""
+skipping each kernel's first `SKIP` dispatches (warm-up).  Kernel names are cut to the bare function name.
+The header comment carries the git blob id of csrc/sfm_kernels.hip as it stands beside this tool (bench.py compares it with the
+source beside the library it loads: `counters_stale`).  Where DIR/meta.json (tools/pmc_ticks.py) says how many Moussaid terms
+the last tick's pair kernel evaluated, a derived row VALU_PER_64_PAIR_STEP = SQ_INSTS_VALU / (terms / 64) is added for the
+pair kernels: what bench.py prices a rank of a sharded run with."""
 import csv
 import glob
+import hashlib
+import json
 import os
 import re
 import sys
@@ -39,7 +45,20 @@ def main():
         for (kernel, counter), v in sorted(vals.items()):
             if v:
                 rows.append((workload, kernel, counter, sum(v) / len(v), len(v)))
+        try:
+            meta = json.load(open(os.path.join(d, "meta.json")))
+        except OSError:
+            meta = None
+        if meta and meta.get("pair_terms"):
+            for kernel in ("sfm_fused_tick_kernel", "sfm_pair_sym_kernel", "sfm_pair_geo_kernel"):
+                v = vals.get((kernel, "SQ_INSTS_VALU"))
+                if v:      # (counters of the LAST launches and the terms of the last tick: the same state to within a tick)
+                    rows.append((workload, kernel, "VALU_PER_64_PAIR_STEP", v[-1] / (meta["pair_terms"] / 64.0), 1))
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "carla-social-force-model_amd", "csrc", "sfm_kernels.hip")
+    data = open(src, "rb").read()
+    blob = hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
     with open(out, "w", newline="") as f:
+        f.write(f"# rocprofv3 --pmc means per launch (tools/pmc_run.sh); sfm_kernels.hip git-blob {blob}\n")
         w = csv.writer(f)
         w.writerow(["workload", "kernel", "counter", "mean_per_launch", "launches"])
         for r in rows:

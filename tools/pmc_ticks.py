@@ -17,4 +17,13 @@ eng = HipShardEngine(default_sfm_config(forces), 0.05)
 eng.load(sc)
 eng.run(ticks)
 eng.synchronize()
+meta = os.environ.get("PMC_META")          # pmc_run.sh: where the summariser finds what the last tick's pair kernel evaluated
+if meta:
+    import json
+    try:
+        items, terms = eng.engine.pair_work()
+    except Exception:
+        items, terms = 0, 0
+    with open(meta, "w") as f:
+        json.dump({"workload": name, "ticks": ticks, "kernel_variant": eng.engine.kernel_variant(), "pair_items": items, "pair_terms": terms}, f)
 eng.close()
