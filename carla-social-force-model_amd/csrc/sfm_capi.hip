@@ -20,7 +20,7 @@ hipError_t launch_arrived(const float4* pk, const float4* own, int N, float thr2
 hipError_t launch_sym_list(const TickArgs& a, const SymArgs& sa, hipStream_t st, int partners = 0, bool count_is_zero = false);
 hipError_t launch_sym_pair(bool rad, const TickArgs& a, const SymArgs& sa, hipStream_t st);
 hipError_t launch_sym_epilogue(bool rad, const TickArgs& a, const SymArgs& sa, hipStream_t st);
-hipError_t launch_fused_tick(bool rad, const TickArgs& a, const FusedArgs& f, hipStream_t st, int waves);
+hipError_t launch_fused_tick(bool rad, const TickArgs& a, const FusedArgs& f, hipStream_t st, int waves, int sys);
 hipError_t launch_sym_pair_geo(bool rad, const TickArgs& a, const SymArgs& sa, hipStream_t st);
 hipError_t launch_schedule(const int* cost, int n_t, uint32_t* work, int* count, hipStream_t st);
 int sym_item_count(int n_t);
@@ -151,8 +151,9 @@ struct SfmHandle {
     int own_alt_cap = 0;
     int pair_geo_mode = -1;                // SFM_PAIR_GEO=0: the geometry kernel always gets a launch of its own (A/B, tests)
     int list_merge_mode = -1;              // SFM_LIST_MERGE=0: the flat tile-pair list always gets a launch of its own (A/B, tests)
-    int fused_mode = -1;                   // SFM_FUSED=0: always the two-kernel tick (A/B, tests)
+    int fused_mode = -1;                   // SFM_FUSED=0: always the two-kernel tick (A/B, tests); 2: the fused tick for a single sfm_run(1) too (tests)
     int fused_waves = 16, fused_blocked = 1;   // SFM_FUSED_WAVES=8 / SFM_FUSED_BLOCKED=0: its A/B variants (tests)
+    int fused_sys = 1;                         // SFM_FUSED_SYS=0: the travelling tile in registers (DPP rotation) instead of LDS (A/B)
     bool used_fused = false;
     // A fused run ends with the partial forces of its final state already in fslab: the next sfm_run / sfm_tick carries on from
     // there (one launch per tick, no start-up launch) provided NOTHING else was called on the handle in between -- api_seq counts
@@ -330,6 +331,8 @@ int sfm_create(const SfmParams* params, int device_id, SfmHandle** out) {
     if (ov && atoi(ov) == 8) h->fused_waves = 8;
     ov = getenv("SFM_FUSED_BLOCKED");
     if (ov) h->fused_blocked = atoi(ov);
+    ov = getenv("SFM_FUSED_SYS");
+    if (ov) h->fused_sys = atoi(ov);
     ov = getenv("SFM_SCHED");
     if (ov) h->sched_mode = atoi(ov);
     ov = getenv("SFM_REORDER");
@@ -1035,7 +1038,7 @@ static int fused_launch(SfmHandle* h, uint32_t flags, int mode, int* sl) {
     fill_args(h, a, flags);
     const FusedArgs f{h->fslab + (size_t)(*sl ^ 1) * rows, h->fslab + (size_t)*sl * rows, h->own, h->own_alt, n_g, h->n_t, h->dpp_dir,
                       (h->fused_blocked != 0 && n_g % 8 == 0) ? 1 : 0, mode};
-    HIP_TRY(h, launch_fused_tick(h->rad, a, f, h->stream, h->fused_waves));
+    HIP_TRY(h, launch_fused_tick(h->rad, a, f, h->stream, h->fused_waves, (h->fused_sys != 0 && h->dpp_dir == 1) ? 1 : 0));
     if (mode != 0) { h->cur ^= 1; std::swap(h->own, h->own_alt); }
     *sl ^= 1;
     return SFM_OK;
@@ -1128,7 +1131,7 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags, int phase = PHASE_
     h->used_fused = false;
     // ---- several ticks of a whole crowd with nothing but the acceleration and pedestrian forces: one launch per tick
     //      (a single tick only when it carries on from a fused run: on its own it would be two launches again)
-    if (sym && whole && plain && phase == PHASE_FULL && (ticks >= 2 || carry) && h->fused_mode != 0 && (flags & SFM_TICK_INTEGRATE) &&
+    if (sym && whole && plain && phase == PHASE_FULL && (ticks >= 2 || carry || h->fused_mode == 2) && h->fused_mode != 0 && (flags & SFM_TICK_INTEGRATE) &&
         !(flags & SFM_TICK_RECORD_FORCES) && !h->fsm_on && h->debug_steps < 0 && !h->stamps && h->n_t >= 4)
         return run_fused(h, ticks, flags, carry);
     // ---- split tick of a shard: what needs only this rank's rows first (sfm_tick_begin), the rest once the exchange is in

@@ -1315,6 +1315,11 @@ __device__ __forceinline__ float rot1(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(b, b, 0x134 /* wave_rol:1 */, 0xf, 0xf, false));
 }
 
+// the same move with nothing kept of the old value: foldable into the VALU instruction that consumes it (v_add_f32_dpp)
+__device__ __forceinline__ float rot_in(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x134 /* wave_rol:1 */, 0xf, 0xf, true));
+}
+
 __global__ void sfm_dpp_probe_kernel(int* out) {       // which way does wave_rol:1 move data?
     const int lane = threadIdx.x & 63;
     out[lane] = __builtin_amdgcn_update_dpp(0, lane, 0x134, 0xf, 0xf, false);
@@ -1875,7 +1880,15 @@ __global__ __launch_bounds__(EW * WAVE) void sfm_sym_epilogue_kernel(const TickA
 // the exact body (by every workgroup that holds them).
 constexpr int GROUP = 2 * WAVE;                  // pedestrians per group of two tiles
 
-template <bool RAD, int NW>                      // NW waves per workgroup (8 or 16): 256 / NW systolic steps each
+// SYS selects how the travelling tile reaches the lanes in the pair phase:
+//   0  in registers, rotated through the wavefront with DPP moves (4 operand moves + 2 accumulator moves per step: sfm_pair_sym_kernel's step)
+//   1  from LDS (round 3): the tile sits in LDS twice back to back, {x, y, lambda vx, lambda vy} per pedestrian, and step s of a lane is
+//      ONE ds_read_b128 at an immediate offset 16 s from the lane's base address -- no operand moves between lanes on the VALU.  Only
+//      the two sums of the travelling side still rotate, and their rotation is folded into the add (v_add_f32_dpp wave_rol:1: the sum
+//      arrives from the neighbouring lane and takes this step's term in one instruction).  60 -> 54 issued VALU instructions per step,
+//      the six v_mov_b32_dpp (half rate) among those gone.  Needs wave_rol:1 to hand lane l the value of lane l+1 (probed at init).
+//      (Measured and dropped: the sums in LDS as well, by ds_add_f32 -- LDS float atomics run at ~2 cycles per LANE: 88.8 against 17.5 us.)
+template <bool RAD, int NW, int SYS>             // NW waves per workgroup (8 or 16): 256 / NW systolic steps each
 __global__ __launch_bounds__(NW * WAVE) void sfm_fused_tick_kernel(const TickArgs a, const FusedArgs f) {
     constexpr int PARTS = NW / 2;                // the slab rows are split over this many 128-thread parts
     constexpr int SPW = 4 * WAVE / NW;           // systolic steps per wave
@@ -1888,6 +1901,8 @@ __global__ __launch_bounds__(NW * WAVE) void sfm_fused_tick_kernel(const TickArg
     __shared__ int s_any;
     __shared__ float2 s_fi[NW][WAVE];
     __shared__ float2 s_fj[NW][WAVE];
+    __shared__ float4 s_trav[SYS ? 4 : 1][2 * WAVE];   // SYS 1: the four tiles as travelling operands, each twice back to back
+    __shared__ float s_radt[(SYS && RAD) ? 4 : 1][2 * WAVE];
     const int tid = threadIdx.x;
     const int lane = tid & (WAVE - 1);
     const int wave = uniform(tid >> 6);
@@ -1959,7 +1974,11 @@ __global__ __launch_bounds__(NW * WAVE) void sfm_fused_tick_kernel(const TickArg
             o = f.own_cur[i];
             if ((a.flags & 2u) && diag_item) { nd0 = a.draws[i]; pid = a.ids ? a.ids[i] : (uint32_t)i; }
         }
-        if (RAD) s_rad[p] = a.radius[i];
+        if (RAD) {
+            const float r_ = a.radius[i];
+            s_rad[p] = r_;
+            if (SYS) { s_radt[(SYS && RAD) ? (p >> 6) : 0][p & (WAVE - 1)] = r_; s_radt[(SYS && RAD) ? (p >> 6) : 0][(p & (WAVE - 1)) + WAVE] = r_; }
+        }
     }
     if (tid == 0) s_any = 0;
     {
@@ -1989,6 +2008,14 @@ __global__ __launch_bounds__(NW * WAVE) void sfm_fused_tick_kernel(const TickArg
     __syncthreads();
     // the arithmetic of sfm_sym_epilogue_kernel without border / obstacle forces (pedestrian_simulation.py:57-83,
     // forces.py:40-52): acceleration towards the waypoint, capped velocity, position, arrival -> next waypoint
+    auto put_state = [&](const float4 ns) {       // pedestrian slot p of the workgroup in the state the pairs are evaluated on
+        s_st[p] = ns;
+        if (SYS) {
+            const float4 t = make_float4(ns.x, ns.y, a.ped.lam * ns.z, a.ped.lam * ns.w);
+            s_trav[p >> 6][p & (WAVE - 1)] = t;
+            s_trav[p >> 6][(p & (WAVE - 1)) + WAVE] = t;
+        }
+    };
     auto finish = [&](const float2 g) {
         const float fpx = a.en_ped ? a.ped.negA * g.x : 0.f, fpy = a.en_ped ? a.ped.negA * g.y : 0.f;
         const float x = st.x, y = st.y, vx = st.z, vy = st.w, ts = o.z;
@@ -2023,7 +2050,7 @@ __global__ __launch_bounds__(NW * WAVE) void sfm_fused_tick_kernel(const TickArg
             f.own_next[i] = make_float4(wx, wy, o.z, o.w);
             a.pk_next[i] = ns;
         }
-        s_st[p] = ns;
+        put_state(ns);
     };
     bool bad = false;
     if (lower && present) {
@@ -2034,7 +2061,7 @@ __global__ __launch_bounds__(NW * WAVE) void sfm_fused_tick_kernel(const TickArg
             bad = a.en_ped && (!(fabsf(g.x) < __builtin_inff()) || !(fabsf(g.y) < __builtin_inff()));
             if (bad) s_any = 1; else finish(g);
         } else {
-            s_st[p] = st;                                            // ghosts, and the first launch of a run: as stored
+            put_state(st);                                           // ghosts, and the first launch of a run: as stored
         }
     }
     if (lower) s_badrow[p] = bad ? 1 : 0;
@@ -2097,7 +2124,40 @@ __global__ __launch_bounds__(NW * WAVE) void sfm_fused_tick_kernel(const TickArg
     }
     float fxi = 0.f, fyi = 0.f, fxj = 0.f, fyj = 0.f;
     int i_end_loc = lane;
-    if (work) {
+    if (work && SYS) {
+        const IxConst& c = a.ped;
+        const float4 pj = s_st[ib + lane];
+        const float ujx = c.lam * pj.z, ujy = c.lam * pj.w;
+        float rj = 0.f;
+        if (RAD) rj = s_rad[ib + lane];
+        // step s meets pedestrian (lane + sig0 + s) mod 64 of the travelling tile: slot lane + sig0 + s of the doubled image
+        const float4* trav = &s_trav[SYS ? (ia >> 6) : 0][lane + sig0];
+        const float* radt = &s_radt[(SYS && RAD) ? (ia >> 6) : 0][lane + sig0];
+        // sigma = 32 on a diagonal tile meets every unordered pair {l, l+32} in BOTH lanes: one-sided there
+        const bool tail_one_sided = diag && (sig0 + SPW - 1 == 32);  // uniform
+        float4 T = trav[0];
+        float ri = RAD ? radt[0] : 0.f;
+#pragma unroll
+        for (int s_ = 0; s_ < SPW; ++s_) {
+            float4 Tn = T;
+            float rin = ri;
+            if (s_ + 1 < SPW) { Tn = trav[s_ + 1]; if (RAD) rin = radt[s_ + 1]; }      // the next step's operand is in flight during this one
+            __builtin_amdgcn_sched_barrier(0);       // (... so its read is issued here, not where the scheduler would sink it to)
+            const float dx = pj.x - T.x, dy = pj.y - T.y;
+            const float d2 = fmaf(dx, dx, dy * dy);
+            float cx, cy;
+            moussaid_planar<RAD, false>(c, dx, dy, d2, T.z - ujx, T.w - ujy, RAD ? ri + rj : 0.f, cx, cy);
+            // the sums of the pedestrian this lane has just met were in lane + 1 a step ago: rotation and add in one instruction
+            fxi = rot_in(fxi) + cx;
+            fyi = rot_in(fyi) + cy;
+            if (s_ + 1 < SPW || !tail_one_sided) { fxj -= cx; fyj -= cy; }
+            T = Tn;
+            ri = rin;
+            __builtin_amdgcn_sched_barrier(0);       // steps are not interleaved: eight waves per SIMD hide a step's chain
+        }
+        i_end_loc = (lane + sig0 + SPW - 1) & (WAVE - 1);
+    }
+    if (work && !SYS) {
         const float4 pj = s_st[ib + lane];
         const int i_loc0 = (lane + f.dir * sig0) & (WAVE - 1);
         const float4 pi0 = s_st[ia + i_loc0];
@@ -2130,24 +2190,25 @@ __global__ __launch_bounds__(NW * WAVE) void sfm_fused_tick_kernel(const TickArg
     __syncthreads();
     if (!lower || !present) return;
     const int tl = (p >> 6) & 1, l = lane;       // tile of the group, pedestrian of the tile
+    auto fi = [&](int w) { return s_fi[w][l]; };   // travelling-side sum of wave w for pedestrian l of its travelling tile
     float2 r = make_float2(0.f, 0.f);
     int row;                                     // partner group = slab row
     if (diag_item) {
         const int w0 = (p < GROUP) ? 0 : NW / 2;
 #pragma unroll
         for (int k = 0; k < D; ++k) {            // the tile's own diagonal item: both sides are this tile
-            const float2 u = s_fi[w0 + tl * D + k][l], v = s_fj[w0 + tl * D + k][l];
+            const float2 u = fi(w0 + tl * D + k), v = s_fj[w0 + tl * D + k][l];
             r.x += u.x + v.x; r.y += u.y + v.y;
         }
 #pragma unroll
         for (int k = 0; k < 2 * D; ++k) {        // the other tile of the group
-            const float2 u = tl ? s_fj[w0 + 2 * D + k][l] : s_fi[w0 + 2 * D + k][l];
+            const float2 u = tl ? s_fj[w0 + 2 * D + k][l] : fi(w0 + 2 * D + k);
             r.x += u.x; r.y += u.y;
         }
         row = G;
     } else if (p < GROUP) {                      // force on GX's pedestrians from GY: the travelling sides
 #pragma unroll
-        for (int k = 0; k < NW / 2; ++k) { const float2 u = s_fi[tl * (NW / 2) + k][l]; r.x += u.x; r.y += u.y; }
+        for (int k = 0; k < NW / 2; ++k) { const float2 u = fi(tl * (NW / 2) + k); r.x += u.x; r.y += u.y; }
         row = GY;
     } else {                                     // force on GY's pedestrians from GX: the resident sides
 #pragma unroll
@@ -2355,16 +2416,19 @@ hipError_t launch_sym_epilogue(bool rad, const TickArgs& a, const SymArgs& sa, h
 }
 
 // one launch of the fused tick (FusedArgs::mode)
-hipError_t launch_fused_tick(bool rad, const TickArgs& a, const FusedArgs& f, hipStream_t st, int nw) {
+hipError_t launch_fused_tick(bool rad, const TickArgs& a, const FusedArgs& f, hipStream_t st, int nw, int sys) {
     if (a.N <= 1 || f.n_g < 2) return hipErrorInvalidValue;
     const int n_g = f.n_g, diag = (n_g + 1) / 2;            // diagonal items, full shifts, the half shift of an even n_g
     const dim3 grid(diag + n_g * ((n_g - 1) / 2) + ((n_g & 1) ? 0 : n_g / 2));
     if (nw == 8) {
-        if (rad) hipLaunchKernelGGL((sfm_fused_tick_kernel<true, 8>), grid, dim3(8 * WAVE), 0, st, a, f);
-        else hipLaunchKernelGGL((sfm_fused_tick_kernel<false, 8>), grid, dim3(8 * WAVE), 0, st, a, f);
+        if (rad) hipLaunchKernelGGL((sfm_fused_tick_kernel<true, 8, 0>), grid, dim3(8 * WAVE), 0, st, a, f);
+        else hipLaunchKernelGGL((sfm_fused_tick_kernel<false, 8, 0>), grid, dim3(8 * WAVE), 0, st, a, f);
+    } else if (sys == 0) {
+        if (rad) hipLaunchKernelGGL((sfm_fused_tick_kernel<true, 16, 0>), grid, dim3(16 * WAVE), 0, st, a, f);
+        else hipLaunchKernelGGL((sfm_fused_tick_kernel<false, 16, 0>), grid, dim3(16 * WAVE), 0, st, a, f);
     } else {
-        if (rad) hipLaunchKernelGGL((sfm_fused_tick_kernel<true, 16>), grid, dim3(16 * WAVE), 0, st, a, f);
-        else hipLaunchKernelGGL((sfm_fused_tick_kernel<false, 16>), grid, dim3(16 * WAVE), 0, st, a, f);
+        if (rad) hipLaunchKernelGGL((sfm_fused_tick_kernel<true, 16, 1>), grid, dim3(16 * WAVE), 0, st, a, f);
+        else hipLaunchKernelGGL((sfm_fused_tick_kernel<false, 16, 1>), grid, dim3(16 * WAVE), 0, st, a, f);
     }
     return hipGetLastError();
 }

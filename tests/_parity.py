@@ -86,4 +86,7 @@ def diagnostics(got, ref, absum, plain, expo):
             "row_rel_p99": float(np.percentile(err / np.maximum(nrm, 1e-300), 99)) if err.size else 0.0,
             "max_amp": float(np.max(np.nan_to_num(absum[ok]) / np.maximum(pl, 1e-300) - 1.0)) if err.size else 0.0,
             "max_expo_rel": float(np.max(np.nan_to_num(expo[ok]) / np.maximum(scale, 1e-300))) if err.size else 0.0,
-            "n_expo": int((np.nan_to_num(expo[ok]) > 0).sum())}
+            "n_expo": int((np.nan_to_num(expo[ok]) > 0).sum()),
+            # per pedestrian against the UNWEIGHTED sum of its term magnitudes (what fp32 rounding of the sum is relative to),
+            # discontinuity allowance taken off: stays meaningful when |F_i| itself is a small difference of large terms
+            "row_over_terms_max": float(np.max(np.maximum(err - np.nan_to_num(expo[ok]) * 1.001 - ATOL, 0.0) / np.maximum(pl, 1e-300))) if err.size else 0.0}
