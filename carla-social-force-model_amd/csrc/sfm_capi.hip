@@ -153,6 +153,7 @@ struct SfmHandle {
     int list_merge_mode = -1;              // SFM_LIST_MERGE=0: the flat tile-pair list always gets a launch of its own (A/B, tests)
     int fused_mode = -1;                   // SFM_FUSED=0: always the two-kernel tick (A/B, tests); 2: the fused tick for a single sfm_run(1) too (tests)
     int fused_waves = 16, fused_blocked = 1;   // SFM_FUSED_WAVES=8 / SFM_FUSED_BLOCKED=0: its A/B variants (tests)
+    int fused_stagger = 0;
     int fused_sys = 1;                         // SFM_FUSED_SYS=0: the travelling tile in registers (DPP rotation) instead of LDS (A/B)
     bool used_fused = false;
     // A fused run ends with the partial forces of its final state already in fslab: the next sfm_run / sfm_tick carries on from
@@ -333,6 +334,8 @@ int sfm_create(const SfmParams* params, int device_id, SfmHandle** out) {
     if (ov) h->fused_blocked = atoi(ov);
     ov = getenv("SFM_FUSED_SYS");
     if (ov) h->fused_sys = atoi(ov);
+    ov = getenv("SFM_FUSED_STAGGER");
+    if (ov) h->fused_stagger = atoi(ov);
     ov = getenv("SFM_SCHED");
     if (ov) h->sched_mode = atoi(ov);
     ov = getenv("SFM_REORDER");
@@ -1037,7 +1040,7 @@ static int fused_launch(SfmHandle* h, uint32_t flags, int mode, int* sl) {
     TickArgs a;
     fill_args(h, a, flags);
     const FusedArgs f{h->fslab + (size_t)(*sl ^ 1) * rows, h->fslab + (size_t)*sl * rows, h->own, h->own_alt, n_g, h->n_t, h->dpp_dir,
-                      (h->fused_blocked != 0 && n_g % 8 == 0) ? 1 : 0, mode};
+                      (h->fused_blocked != 0 && n_g % 8 == 0) ? 1 : 0, h->fused_stagger, mode};
     HIP_TRY(h, launch_fused_tick(h->rad, a, f, h->stream, h->fused_waves, (h->fused_sys != 0 && h->dpp_dir == 1) ? 1 : 0));
     if (mode != 0) { h->cur ^= 1; std::swap(h->own, h->own_alt); }
     *sl ^= 1;
@@ -1580,12 +1583,14 @@ int sfm_download_draw_counts(SfmHandle* h, uint32_t* counts) {
     return SFM_OK;
 }
 
-// A device pointer handed out: the caller may write the rows through it, so nothing derived from the stored state survives --
-// the fused tick's partial forces, the tile boxes the last epilogue left for the next tick's list, geometry forces launched ahead.
+// A device pointer handed out: the caller may write rows through it, so what was derived from the stored state does not survive:
+// the fused tick's partial forces and the tile boxes the last epilogue left for the next tick's list.  On a WHOLE-crowd handle
+// also geometry forces launched ahead.  A shard's protocol is that the caller writes the OTHER ranks' rows only (the exchange):
+// its geometry forces launched ahead and a begun split tick (sfm_tick_begin) read nothing but own rows and stay.
 static void caller_may_write(SfmHandle* h) {
     h->carry_ok = false;
     h->boxes_valid = false;
-    drop_geo_ahead(h);
+    if (h->i_begin == 0 && h->i_end == h->N) drop_geo_ahead(h);
 }
 
 void* sfm_packed_state_ptr(SfmHandle* h, int* n_pad) {

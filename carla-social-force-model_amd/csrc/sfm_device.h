@@ -159,6 +159,7 @@ struct FusedArgs {
     int n_t;
     int dir;                  // as SymArgs::dir
     int blocked;              // 1: XCD-aware order of the work items (n_g a multiple of 8)
+    int stagger;              // experiment (SFM_FUSED_STAGGER): the second workgroup of a CU waits this many x 0.25 us before its column sums
     int mode;                 // 0: the stored state is the state (nothing to integrate, nothing stored but slab_next): the launch in
                               //    front of a run; 1: integrate by one tick, store, then the pairs of the new state
 };

@@ -1329,6 +1329,8 @@ struct PairShared {                             // LDS of one pair workgroup
     float2 fi[WAVES_PER_BLOCK][WAVE];
     float2 fj[WAVES_PER_BLOCK][WAVE];
     int cnt[WAVES_PER_BLOCK];
+    float4 trav[2][2 * WAVE];                   // the travelling tile(s) {x, y, lambda vx, lambda vy}, each twice back to back (two: a diagonal item)
+    float radt[2][2 * WAVE];                    // ... and their radii (use_ped_radius)
 };
 
 // The body of sfm_pair_sym_kernel for workgroup (bid_x, bid_y) of a grid grid_x wide, callable from another kernel's workgroups as
@@ -1383,58 +1385,72 @@ __device__ __forceinline__ void pair_block(const float4* __restrict__ pk, const 
     int i_end_loc = lane;
     int executed = 0;                             // systolic steps this wave evaluated (uniform)
     bool negligible = false;                      // lite cutoff: the whole tile pair is provably below 2^-40 A
+    // The travelling tile goes through LDS (round 3): one wave stages it, twice back to back and with lambda v folded in, and
+    // step s of a lane is one ds_read_b128 at slot lane + sig0 + s -- no operand moves between lanes on the VALU; only the two
+    // travelling sums still rotate, inside the add that takes the step's term (v_add_f32_dpp).  54 instead of 60 VALU per step.
+    const int tsel = diag ? (wave >> 1) : 0;
+    if (ta >= 0 && (wave == 0 || (diag && wave == 2))) {
+        const float4 q = pk[ta * WAVE + lane];
+        const float4 t = make_float4(q.x, q.y, c.lam * q.z, c.lam * q.w);
+        sh.trav[tsel][lane] = t; sh.trav[tsel][lane + WAVE] = t;
+        if (RAD) { const float r_ = radius[ta * WAVE + lane]; sh.radt[tsel][lane] = r_; sh.radt[tsel][lane + WAVE] = r_; }
+    }
+    __syncthreads();
     if (ta >= 0) {
         const float4 pj = pk[tb * WAVE + lane];
-        const int i_loc0 = (lane + sa.dir * sig0) & (WAVE - 1);
-        const float4 pi0 = pk[ta * WAVE + i_loc0];
-        float rj = 0.f, ri = 0.f;                    // use_ped_radius: the radii travel with their pedestrians
-        if (RAD) { rj = radius[tb * WAVE + lane]; ri = radius[ta * WAVE + i_loc0]; }
+        float rj = 0.f;
+        if (RAD) rj = radius[tb * WAVE + lane];
         float reach2 = __builtin_inff();             // CUT: squared distance beyond which a term is < 2^-40 A (uniform)
         if (CUT && shift != 0) {
-            // lite cutoff (tested while the two loads above are in flight): every term of this tile pair is provably
-            // < 2^-40 A -> nothing to do; the epilogue applies the same test and does not read this pair's slab rows
+            // lite cutoff: every term of this tile pair is provably < 2^-40 A -> nothing to do; the epilogue applies the same
+            // test and does not read this pair's slab rows
             negligible = sa.box && tiles_negligible(sa.box[ta], sa.vmax[ta], sa.box[tb], sa.vmax[tb], c.lam, sa.cut_scale, sa.cut_pad);
             const float reach = fmaf(sa.cut_scale, fmaf(c.lam, sa.vmax[ta] + sa.vmax[tb], 1.0f), sa.cut_pad);
             reach2 = reach * reach;
         }
       if (!negligible) {
         // lambda v travels with i / stays with j: D = lambda (v_i - v_j) + e is then one fma per component
-        float xi = pi0.x, yi = pi0.y, uxi = c.lam * pi0.z, uyi = c.lam * pi0.w;
         const float ujx = c.lam * pj.z, ujy = c.lam * pj.w;
-        auto step = [&](bool both) {
-            const float dx = pj.x - xi, dy = pj.y - yi;
+        const float4* trav = &sh.trav[tsel][lane + sig0];
+        const float* radt = &sh.radt[tsel][lane + sig0];
+        // sigma = 32 on a diagonal tile meets every unordered pair {l, l+32} in BOTH lanes: one-sided there
+        const int one_sided_from = one_sided ? 0 : ((diag && (sig0 + nsteps - 1 == 32)) ? nsteps - 1 : nsteps);   // uniform
+        float4 T = trav[0];
+        float ri = RAD ? radt[0] : 0.f;
+        // (steps are not interleaved: measured on MI355X, round 2 -- eight waves per SIMD already hide a step's dependent chain;
+        //  unrolled by four only so that the slot offsets are immediates of the LDS reads)
+        auto step = [&](int s_) __attribute__((always_inline)) {
+            const float4 Tn = trav[s_ + 1];       // the next step's operand is in flight during this one (slot <= 127: inside the image)
+            float rin = 0.f;
+            if (RAD) rin = radt[s_ + 1];
+            __builtin_amdgcn_sched_barrier(0);
+            const float dx = pj.x - T.x, dy = pj.y - T.y;
             const float d2 = fmaf(dx, dx, dy * dy);
+            bool done = false;
             if (!CUT || __any(!(d2 > reach2))) {
                 float cx, cy;
-                if (moussaid_planar<RAD, CUT>(c, dx, dy, d2, uxi - ujx, uyi - ujy, RAD ? ri + rj : 0.f, cx, cy)) {
-                    fxi += cx;
-                    fyi += cy;
-                    if (both) { fxj -= cx; fyj -= cy; }
+                if (moussaid_planar<RAD, CUT>(c, dx, dy, d2, T.z - ujx, T.w - ujy, RAD ? ri + rj : 0.f, cx, cy)) {
+                    // the sums of the pedestrian this lane has just met were in lane + 1 a step ago: rotation and add in one
+                    fxi = rot_in(fxi) + cx;
+                    fyi = rot_in(fyi) + cy;
+                    if (s_ < one_sided_from) { fxj -= cx; fyj -= cy; }
                     ++executed;
+                    done = true;
                 }
             }
-            xi = rot1(xi); yi = rot1(yi); uxi = rot1(uxi); uyi = rot1(uyi);
-            if (RAD) ri = rot1(ri);
-            fxi = rot1(fxi); fyi = rot1(fyi);
+            if (CUT && !done) { fxi = rot_in(fxi); fyi = rot_in(fyi); }
+            T = Tn;
+            ri = rin;
+            __builtin_amdgcn_sched_barrier(0);
         };
-        // sigma = 32 on a diagonal tile meets every unordered pair {l, l+32} in BOTH lanes: one-sided there
-        const bool tail_one_sided = diag && (sig0 + nsteps - 1 == 32);        // uniform
-        // (not unrolled: measured on MI355X, round 2 -- c2 pair kernel 14.96 us at unroll 1, 16.7 / 15.6 / 16.7 / 15.9 at 2 / 3 / 4 / 5;
-        //  c5 854 against 896 us per tick at 3.  Eight waves per SIMD already hide a step's dependent chain; interleaving steps in
-        //  one wave only costs registers and a longer schedule.)
         if (nsteps == 16) {                      // the normal case: fixed trip count
-            if (one_sided) {
-#pragma unroll 1
-                for (int s = 0; s < 16; ++s) step(false);
-            } else {
-#pragma unroll 1
-                for (int s = 0; s < 15; ++s) step(true);
-                if (tail_one_sided) step(false); else step(true);
-            }
+#pragma unroll 4
+            for (int s_ = 0; s_ < 16; ++s_) step(s_);
         } else {                                 // timing probe (SymArgs::debug_steps)
-            for (int s = 0; s < nsteps; ++s) step(true);
+#pragma unroll 1
+            for (int s_ = 0; s_ < nsteps; ++s_) step(s_);
         }
-        i_end_loc = (lane + sa.dir * (sig0 + nsteps)) & (WAVE - 1);
+        i_end_loc = (lane + sig0 + nsteps - 1) & (WAVE - 1);
       }
     }
     sh.fi[wave][i_end_loc] = make_float2(fxi, fyi);
@@ -1987,6 +2003,8 @@ __global__ __launch_bounds__(NW * WAVE) void sfm_fused_tick_kernel(const TickArg
         const int Gq = (2 * pp < GROUP) ? GX : GY;
         const int i2 = Gq * GROUP + ((2 * pp) & (GROUP - 1));
         float4 acc4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (f.stagger > 0 && integrate && blockIdx.x >= 256u)
+            for (int k = 0; k < f.stagger; ++k) __builtin_amdgcn_s_sleep(8);
         if (integrate && a.en_ped && Gq < n_g && i2 < a.N) {
             const float4* col = reinterpret_cast<const float4*>(f.slab_prev + i2);
             const size_t stride4 = (size_t)a.N_pad / 2;
