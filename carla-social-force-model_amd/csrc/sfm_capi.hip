@@ -21,6 +21,7 @@ hipError_t launch_sym_list(const TickArgs& a, const SymArgs& sa, hipStream_t st,
 hipError_t launch_sym_pair(bool rad, const TickArgs& a, const SymArgs& sa, hipStream_t st);
 hipError_t launch_sym_epilogue(bool rad, const TickArgs& a, const SymArgs& sa, hipStream_t st);
 hipError_t launch_fused_tick(bool rad, const TickArgs& a, const FusedArgs& f, hipStream_t st, int waves, int sys);
+int fused_pair_workgroups(int n_g);
 hipError_t launch_sym_pair_geo(bool rad, const TickArgs& a, const SymArgs& sa, hipStream_t st);
 hipError_t launch_schedule(const int* cost, int n_t, uint32_t* work, int* count, hipStream_t st);
 int sym_item_count(int n_t);
@@ -151,9 +152,15 @@ struct SfmHandle {
     int own_alt_cap = 0;
     int pair_geo_mode = -1;                // SFM_PAIR_GEO=0: the geometry kernel always gets a launch of its own (A/B, tests)
     int list_merge_mode = -1;              // SFM_LIST_MERGE=0: the flat tile-pair list always gets a launch of its own (A/B, tests)
-    int fused_mode = -1;                   // SFM_FUSED=0: always the two-kernel tick (A/B, tests); 2: the fused tick for a single sfm_run(1) too (tests)
+    int fused_mode = -1;                   // SFM_FUSED=0: always the two-kernel tick (A/B, tests)
     int fused_waves = 16, fused_blocked = 1;   // SFM_FUSED_WAVES=8 / SFM_FUSED_BLOCKED=0: its A/B variants (tests)
-    int fused_stagger = 0;
+    float2* fgeo = nullptr;                // [2][4][N_pad] border + obstacle forces of the fused tick, one float2 per pedestrian and slice, ping-pong
+    size_t fgeo_cap = 0;
+    float4* dyn_ctr_alt = nullptr;         // device-side vehicles in the fused tick: the NEXT tick's centres / rings (ping-pong with dynamics.ctr / .pts)
+    float2* dyn_pts_alt = nullptr;
+    size_t dyn_ctr_alt_cap = 0, dyn_pts_alt_cap = 0;
+    int fused_geo_slices = 0;              // SFM_FUSED_GEO_SLICES: A/B
+    int fused_geo_mode = -1;               // SFM_FUSED_GEO=0: crowds with border / obstacle forces keep the two-launch tick (A/B, tests)
     int fused_sys = 1;                         // SFM_FUSED_SYS=0: the travelling tile in registers (DPP rotation) instead of LDS (A/B)
     bool used_fused = false;
     // A fused run ends with the partial forces of its final state already in fslab: the next sfm_run / sfm_tick carries on from
@@ -334,8 +341,10 @@ int sfm_create(const SfmParams* params, int device_id, SfmHandle** out) {
     if (ov) h->fused_blocked = atoi(ov);
     ov = getenv("SFM_FUSED_SYS");
     if (ov) h->fused_sys = atoi(ov);
-    ov = getenv("SFM_FUSED_STAGGER");
-    if (ov) h->fused_stagger = atoi(ov);
+    ov = getenv("SFM_FUSED_GEO");
+    if (ov) h->fused_geo_mode = atoi(ov);
+    ov = getenv("SFM_FUSED_GEO_SLICES");
+    if (ov) h->fused_geo_slices = atoi(ov);
     ov = getenv("SFM_SCHED");
     if (ov) h->sched_mode = atoi(ov);
     ov = getenv("SFM_REORDER");
@@ -405,6 +414,9 @@ int sfm_destroy(SfmHandle* h) {
     if (h->dyn_rot) hipFree(h->dyn_rot);
     if (h->slab) hipFree(h->slab);
     if (h->fslab) hipFree(h->fslab);
+    if (h->fgeo) hipFree(h->fgeo);
+    if (h->dyn_ctr_alt) hipFree(h->dyn_ctr_alt);
+    if (h->dyn_pts_alt) hipFree(h->dyn_pts_alt);
     if (h->own_alt) hipFree(h->own_alt);
     for (void* q : {(void*)h->f_mode, (void*)h->f_target, (void*)h->f_initial, (void*)h->f_crossing, (void*)h->f_margin,
                     (void*)h->f_next, (void*)h->f_off, (void*)h->f_cursor, (void*)h->f_xy, (void*)h->f_cross})
@@ -1039,10 +1051,40 @@ static int fused_launch(SfmHandle* h, uint32_t flags, int mode, int* sl) {
     const size_t rows = (size_t)n_g * (size_t)h->N_pad;
     TickArgs a;
     fill_args(h, a, flags);
+    const bool geo = a.geo != nullptr;
+    int slices = 0, nw = h->fused_waves;
+    const int n_pair = fused_pair_workgroups(n_g);
+    if (geo) {
+        slices = h->fused_geo_slices > 0 ? std::min(4, h->fused_geo_slices) : (h->n_t <= 64 ? 4 : 2);
+        // two 16-wave workgroups fill a CU: when pair + geometry workgroups do not fit in 512 such slots the launch runs 8-wave
+        // workgroups (four per CU; the pair phase is within a few per cent at 4 waves per SIMD)
+        if (n_pair + h->n_t * slices > 512) nw = 8;
+    }
+    const size_t grow = (size_t)4 * (size_t)h->N_pad;
+    // device-side vehicles: this launch's geometry workgroups read the vehicles at the time of the state they evaluate; its vehicle
+    // workgroups write the next tick's into the other half.  Launch in front (mode 0): reads the stored ones, writes the alternate.
+    // An integrating launch evaluates the NEXT state: reads the alternate, overwrites the stored half -- and then they swap.
+    if (geo && a.adv.M > 0) {
+        float4* c_in = mode ? h->dyn_ctr_alt : h->dynamics.ctr;
+        float2* p_in = mode ? h->dyn_pts_alt : h->dynamics.pts;
+        a.dynamics.ctr = c_in; a.dynamics.pts = p_in;
+        a.adv.ctr = c_in; a.adv.pts = p_in;
+        a.adv.ctr_out = mode ? h->dynamics.ctr : h->dyn_ctr_alt;
+        a.adv.pts_out = mode ? h->dynamics.pts : h->dyn_pts_alt;
+    }
     const FusedArgs f{h->fslab + (size_t)(*sl ^ 1) * rows, h->fslab + (size_t)*sl * rows, h->own, h->own_alt, n_g, h->n_t, h->dpp_dir,
-                      (h->fused_blocked != 0 && n_g % 8 == 0) ? 1 : 0, h->fused_stagger, mode};
-    HIP_TRY(h, launch_fused_tick(h->rad, a, f, h->stream, h->fused_waves, (h->fused_sys != 0 && h->dpp_dir == 1) ? 1 : 0));
-    if (mode != 0) { h->cur ^= 1; std::swap(h->own, h->own_alt); }
+                      (h->fused_blocked != 0 && n_g % 8 == 0) ? 1 : 0,
+                      geo ? h->fgeo + (size_t)(*sl ^ 1) * grow : nullptr, geo ? h->fgeo + (size_t)*sl * grow : nullptr, slices,
+                      geo ? h->n_t * slices : 0, n_pair, mode};
+    HIP_TRY(h, launch_fused_tick(h->rad, a, f, h->stream, nw, (h->fused_sys != 0 && h->dpp_dir == 1) ? 1 : 0));
+    if (mode != 0) {
+        h->cur ^= 1;
+        std::swap(h->own, h->own_alt);
+        if (geo && a.adv.M > 0) {
+            std::swap(h->dynamics.ctr, h->dyn_ctr_alt); std::swap(h->dynamics.ctr_cap, h->dyn_ctr_alt_cap);
+            std::swap(h->dynamics.pts, h->dyn_pts_alt); std::swap(h->dynamics.pts_cap, h->dyn_pts_alt_cap);
+        }
+    }
     *sl ^= 1;
     return SFM_OK;
 }
@@ -1051,23 +1093,41 @@ static int fused_reserve(SfmHandle* h) {
     const size_t need = (size_t)2 * (size_t)((h->n_t + 1) / 2) * (size_t)h->N_pad;
     if (need > h->fslab_cap) { HIP_TRY(h, dev_realloc(h->fslab, need)); h->fslab_cap = need; }
     if (h->own_alt_cap < h->cap) { HIP_TRY(h, dev_realloc(h->own_alt, (size_t)h->cap)); h->own_alt_cap = h->cap; }   // same size as own: they swap
+    const size_t gneed = (size_t)2 * 4 * (size_t)h->N_pad;
+    if (gneed > h->fgeo_cap) { HIP_TRY(h, dev_realloc(h->fgeo, gneed)); h->fgeo_cap = gneed; }
+    if (h->dyn_boxes && h->dynamics.K > 0) {             // the vehicles' other half: same capacities as the stored one (they swap)
+        if (h->dyn_ctr_alt_cap != h->dynamics.ctr_cap) { HIP_TRY(h, dev_realloc(h->dyn_ctr_alt, std::max<size_t>(1, h->dynamics.ctr_cap))); h->dyn_ctr_alt_cap = h->dynamics.ctr_cap; }
+        if (h->dyn_pts_alt_cap != h->dynamics.pts_cap) { HIP_TRY(h, dev_realloc(h->dyn_pts_alt, std::max<size_t>(1, h->dynamics.pts_cap))); h->dyn_pts_alt_cap = h->dynamics.pts_cap; }
+    }
     return SFM_OK;
 }
 
-// `ticks` ticks of a whole planar crowd with acceleration + pedestrian force only, one launch each.  `carry`: the previous call on
-// this handle was such a run too, its last launch left the partial forces of the current state in fslab; otherwise one launch
-// in front evaluates them.  Either way the run ends with state AND partial forces current.
-static int run_fused(SfmHandle* h, int ticks, uint32_t flags, bool carry) {
+// `ticks` ticks of a whole planar crowd below the list cutoff, one launch each.  `carry`: the previous call on this handle was such
+// a run too, its last launch left the partial forces of the current state in fslab (fgeo); otherwise one launch in front
+// evaluates them.  Either way the run ends with state AND partial forces current.  With border / obstacle forces the rows are
+// re-packed every resort_every ticks (compact tiles are what the geometry workgroups' culls live on), each re-pack followed by a
+// launch in front again (the partial forces are per row).
+static int run_fused(SfmHandle* h, int ticks, uint32_t flags, bool carry, bool geo) {
     int rc = fused_reserve(h);
     if (rc) return rc;
-    snprintf(h->variant, sizeof(h->variant), "sfm_fused_tick_kernel");
+    snprintf(h->variant, sizeof(h->variant), geo ? "sfm_fused_tick_kernel(geo)" : "sfm_fused_tick_kernel");
     if (h->timing_on) HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
     int sl = carry ? h->carry_sl : 0;
-    if (!carry) rc = fused_launch(h, flags, 0, &sl);
-    for (int t = 0; t < ticks && rc == SFM_OK; ++t) rc = fused_launch(h, flags, 1, &sl);
+    bool front = !carry;
+    int launches = 0;
+    for (int t = 0; t < ticks && rc == SFM_OK; ++t) {
+        if (geo && h->reordered && h->resort_every > 0 && h->ticks_since_sort >= h->resort_every) {
+            rc = resort_rows(h);
+            if (rc) return rc;
+            launches += 5;
+            front = true;
+        }
+        if (front) { rc = fused_launch(h, flags, 0, &sl); ++launches; front = false; }
+        if (rc == SFM_OK) { rc = fused_launch(h, flags, 1, &sl); ++launches; }
+        ++h->ticks_since_sort;
+    }
     if (rc) return rc;
     if (h->timing_on) HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
-    h->ticks_since_sort += ticks;
     h->used_fused = true;
     h->carry_ok = true;
     h->carry_seq = h->api_seq;
@@ -1076,7 +1136,7 @@ static int run_fused(SfmHandle* h, int ticks, uint32_t flags, bool carry) {
     h->boxes_valid = false;
     h->count_zeroed = false;
     h->timed_ticks = ticks;
-    h->timed_launches = ticks + (carry ? 0 : 1);
+    h->timed_launches = launches;
     h->timing_valid = h->timing_on;
     h->rec_valid = false;
     return SFM_OK;
@@ -1093,7 +1153,7 @@ static int merged_geo_slices(int tiles, int slices) {
     return tiles >= 1024 ? 1 : tiles >= 64 ? 4 : tiles > 32 ? 8 : 16;
 }
 
-static int run_ticks(SfmHandle* h, int ticks, uint32_t flags, int phase = PHASE_FULL) {
+static int run_ticks(SfmHandle* h, int ticks, uint32_t flags, int phase = PHASE_FULL, bool device_run = false) {
     int rc = bind(h);
     if (rc) return rc;
     const bool carry = h->carry_ok && h->api_seq == h->carry_seq + 1;     // the call before this one was a fused run, nothing in between
@@ -1111,13 +1171,14 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags, int phase = PHASE_
     strip_shape(h, &tps, &n_strips);
     // symmetric path: planar crowd, the whole of it on this handle or a tile-aligned shard; auto mode wants >= 4 tiles
     const size_t need = (size_t)h->n_t * (size_t)slab_stride(h->n_t);
-    bool order_pays, list_cut, plain;               // compact tiles only matter to the tile cutoff and the geometry kernel
+    bool order_pays, list_cut, plain, fused_geo;    // compact tiles only matter to the tile cutoff and the geometry kernel
     {
         TickArgs probe;
         fill_args(h, probe, flags);
         order_pays = probe.geo != nullptr || probe.tile_box != nullptr;
         list_cut = probe.tile_box != nullptr && !probe.lite;
         plain = probe.geo == nullptr && probe.tile_box == nullptr && probe.adv.M == 0;
+        fused_geo = probe.geo != nullptr && probe.tile_box == nullptr && h->fused_geo_mode != 0;
     }
     // a shard can use it too when its rows are whole tiles and the tile-pair list is on: pairs with a tile of another
     // rank are then evaluated one-sided by both ranks
@@ -1133,10 +1194,13 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags, int phase = PHASE_
                   h->rad ? "true" : "false", team);
     h->used_fused = false;
     // ---- several ticks of a whole crowd with nothing but the acceleration and pedestrian forces: one launch per tick
-    //      (a single tick only when it carries on from a fused run: on its own it would be two launches again)
-    if (sym && whole && plain && phase == PHASE_FULL && (ticks >= 2 || carry || h->fused_mode == 2) && h->fused_mode != 0 && (flags & SFM_TICK_INTEGRATE) &&
-        !(flags & SFM_TICK_RECORD_FORCES) && !h->fsm_on && h->debug_steps < 0 && !h->stamps && h->n_t >= 4)
-        return run_fused(h, ticks, flags, carry);
+    //      Every sfm_run / sfm_run_recorded takes it, whatever its length -- what a device-resident run computes must not depend on
+    //      how the caller cuts it into calls (a lone sfm_run(1) pays a launch in front like the two-launch tick pays its epilogue) --
+    //      and a single sfm_tick when it carries on from such a run.
+    if (sym && whole && (plain || fused_geo) && phase == PHASE_FULL && (device_run || carry) && h->fused_mode != 0 &&
+        (flags & SFM_TICK_INTEGRATE) && !(flags & SFM_TICK_RECORD_FORCES) && !h->fsm_on && h->debug_steps < 0 && !h->stamps && !h->geo_stamps &&
+        h->n_t >= 4)
+        return run_fused(h, ticks, flags, carry, fused_geo);
     // ---- split tick of a shard: what needs only this rank's rows first (sfm_tick_begin), the rest once the exchange is in
     //      (sfm_tick_end).  Anything else: sfm_tick_begin does nothing and sfm_tick_end runs the whole tick.
     if (phase == PHASE_BEGIN) {
@@ -1352,6 +1416,16 @@ int sfm_profile_dominant_kernel(SfmHandle* h, int reps, float* avg_us) {
             ~Keep() { if (a) hipFree(a); if (b) hipFree(b); if (c) hipFree(c); }
         } keep{pk_keep, own_keep, draws_keep};
         HIP_TRY(h, dev_realloc(pk_keep, np_)); HIP_TRY(h, dev_realloc(own_keep, np_)); HIP_TRY(h, dev_realloc(draws_keep, np_));
+        // vehicles that move on the device move in these launches too: their centres and rings are put back as well
+        const bool veh = h->dyn_boxes && h->dynamics.K > 0;
+        float4* ctr_keep = nullptr;
+        float2* pts_keep = nullptr;
+        struct KeepV { float4*& a; float2*& b; ~KeepV() { if (a) hipFree(a); if (b) hipFree(b); } } keepv{ctr_keep, pts_keep};
+        if (veh) {
+            HIP_TRY(h, dev_realloc(ctr_keep, (size_t)h->dynamics.K)); HIP_TRY(h, dev_realloc(pts_keep, (size_t)std::max(1, h->dynamics.P)));
+            HIP_TRY(h, hipMemcpyAsync(ctr_keep, h->dynamics.ctr, sizeof(float4) * (size_t)h->dynamics.K, hipMemcpyDeviceToDevice, h->stream));
+            HIP_TRY(h, hipMemcpyAsync(pts_keep, h->dynamics.pts, sizeof(float2) * (size_t)h->dynamics.P, hipMemcpyDeviceToDevice, h->stream));
+        }
         HIP_TRY(h, hipMemcpyAsync(pk_keep, h->pk[h->cur], sizeof(float4) * np_, hipMemcpyDeviceToDevice, h->stream));
         HIP_TRY(h, hipMemcpyAsync(own_keep, h->own, sizeof(float4) * np_, hipMemcpyDeviceToDevice, h->stream));
         HIP_TRY(h, hipMemcpyAsync(draws_keep, h->draws, sizeof(uint32_t) * np_, hipMemcpyDeviceToDevice, h->stream));
@@ -1368,6 +1442,10 @@ int sfm_profile_dominant_kernel(SfmHandle* h, int reps, float* avg_us) {
         HIP_TRY(h, hipMemcpyAsync(h->pk[h->cur], pk_keep, sizeof(float4) * np_, hipMemcpyDeviceToDevice, h->stream));
         HIP_TRY(h, hipMemcpyAsync(h->own, own_keep, sizeof(float4) * np_, hipMemcpyDeviceToDevice, h->stream));
         HIP_TRY(h, hipMemcpyAsync(h->draws, draws_keep, sizeof(uint32_t) * np_, hipMemcpyDeviceToDevice, h->stream));
+        if (veh) {
+            HIP_TRY(h, hipMemcpyAsync(h->dynamics.ctr, ctr_keep, sizeof(float4) * (size_t)h->dynamics.K, hipMemcpyDeviceToDevice, h->stream));
+            HIP_TRY(h, hipMemcpyAsync(h->dynamics.pts, pts_keep, sizeof(float2) * (size_t)h->dynamics.P, hipMemcpyDeviceToDevice, h->stream));
+        }
         HIP_TRY(h, hipEventSynchronize(h->ev1));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         float ms = 0.f;
@@ -1413,7 +1491,7 @@ int sfm_tick_begin(SfmHandle* h, uint32_t flags) { return run_ticks(h, 1, flags 
 
 int sfm_tick_end(SfmHandle* h, uint32_t flags) { return run_ticks(h, 1, flags | SFM_TICK_INTEGRATE, PHASE_END); }
 
-int sfm_run(SfmHandle* h, int ticks, uint32_t flags) { return run_ticks(h, ticks, flags | SFM_TICK_INTEGRATE); }
+int sfm_run(SfmHandle* h, int ticks, uint32_t flags) { return run_ticks(h, ticks, flags | SFM_TICK_INTEGRATE, PHASE_FULL, true); }
 
 int sfm_run_recorded(SfmHandle* h, int ticks, uint32_t flags, int stride, float* frames, int max_frames, int* n_frames) {
     int rc = bind(h);
@@ -1442,7 +1520,7 @@ int sfm_run_recorded(SfmHandle* h, int ticks, uint32_t flags, int stride, float*
             ++f;
         }
         const int chunk = std::min(stride, ticks - done);
-        rc = run_ticks(h, chunk, flags | SFM_TICK_INTEGRATE);
+        rc = run_ticks(h, chunk, flags | SFM_TICK_INTEGRATE, PHASE_FULL, true);
         done += chunk;
     }
     if (rc == SFM_OK && hipStreamSynchronize(h->stream) != hipSuccess) rc = fail(h, SFM_ERR_HIP, "hipStreamSynchronize failed");

@@ -67,6 +67,8 @@ struct DynAdvance {
     int M;
     float dt;
     int block0;
+    float4* ctr_out;          // fused tick with border / obstacle forces: the moved centres and rings go to the other half of a
+    float2* pts_out;          // ping-pong (this launch's geometry workgroups still read ctr / pts); null: in place
 };
 
 struct TickArgs {
@@ -159,7 +161,11 @@ struct FusedArgs {
     int n_t;
     int dir;                  // as SymArgs::dir
     int blocked;              // 1: XCD-aware order of the work items (n_g a multiple of 8)
-    int stagger;              // experiment (SFM_FUSED_STAGGER): the second workgroup of a CU waits this many x 0.25 us before its column sums
+    const float2* geo_prev;   // [geo_slices][N_pad]: border + obstacle forces on the stored state, one partial sum per slice of the polylines
+    float2* geo_next;         // the same for the state this launch integrates to
+    int geo_slices;           // <= 4
+    int n_geo_wg;             // geometry workgroups in front of the grid = n_t * geo_slices (0: the crowd has no such forces)
+    int n_pair_wg;            // pair workgroups behind them
     int mode;                 // 0: the stored state is the state (nothing to integrate, nothing stored but slab_next): the launch in
                               //    front of a run; 1: integrate by one tick, store, then the pairs of the new state
 };

@@ -200,13 +200,14 @@ __device__ __forceinline__ void advance_vehicle(const DynAdvance& d, int k, int 
     if (advance) {
         c.x = fmaf(d.dt, c.z, c.x);
         c.y = fmaf(d.dt, c.w, c.y);
-        if (lane == 0) d.ctr[k] = c;
+        if (lane == 0) (d.ctr_out ? d.ctr_out : d.ctr)[k] = c;
     }
     const float2 r = d.rot[k];                     // {cos yaw, sin yaw}
     const int o1 = d.off[k + 1];
+    float2* pts = d.pts_out ? d.pts_out : d.pts;
     for (int p = d.off[k] + lane; p < o1; p += WAVE) {
         const float2 u = d.local[p];
-        d.pts[p] = make_float2(fmaf(r.x, u.x, fmaf(-r.y, u.y, c.x)), fmaf(r.y, u.x, fmaf(r.x, u.y, c.y)));
+        pts[p] = make_float2(fmaf(r.x, u.x, fmaf(-r.y, u.y, c.x)), fmaf(r.y, u.x, fmaf(r.x, u.y, c.y)));
     }
 }
 
@@ -527,27 +528,15 @@ struct GeoShared {                              // LDS of one geometry workgroup
     int count[GW];
 };
 
-// The border / obstacle forces of tile (a.i_begin / 64 + bx), slice slice_y of n_slices: the body of sfm_geometry_kernel, callable
-// from another kernel's workgroups as well (sfm_pair_geo_kernel).  n_bx only places the diagnostic stamps.
+// The border / obstacle forces on the 64 pedestrians `me` (one per lane, the same in every wave of the workgroup), slice `slice` of
+// n_slices of the polylines: find, then scan.  Leaves every wave's partial sums in sh.acc[wave][6][lane]
+// ({border x, y, static x, y, dynamic x, y}, the obstacle terms still without their factor -A) behind a workgroup barrier.
 template <bool RAD, int GW>
-__device__ __forceinline__ void geometry_block(const TickArgs& a, GeoShared<GW>& sh, int bx, int slice_y, int n_slices, int n_bx, int tid) {
+__device__ __forceinline__ void geometry_forces(const TickArgs& a, GeoShared<GW>& sh, GeoLane& me, int slice, int n_slices, int tid,
+                                                unsigned long long* st1) {
     const int lane = tid & (WAVE - 1);
     const int wave = uniform((int)(tid >> 6));
-    unsigned long long st0 = 0, st1 = 0, st2 = 0;
-    if (a.geo_stamps) st0 = __builtin_amdgcn_s_memrealtime();
-    const int t = (a.i_begin >> 6) + bx;                      // tile index
-    const int p0 = max(a.i_begin, t * WAVE), p1 = min(a.i_end, (t + 1) * WAVE);
-    const int i = t * WAVE + lane;
-    GeoLane me;
-    me.live = i >= p0 && i < p1;
-    me.x = 3.0e15f; me.y = 3.0e15f; me.vx = 0.f; me.vy = 0.f; me.r = 0.f;
-    if (me.live) {
-        const float4 s = a.pk_cur[i];
-        me.x = s.x; me.y = s.y; me.vx = s.z; me.vy = s.w;
-        me.r = a.own[i].w;
-    }
     const float inf = __builtin_inff();
-    me.walk = me.live && !(a.crossing && a.crossing[i]);              // forces.py:140-141,176-177
     me.skip = a.border_skip > 0.0f ? a.border_skip + (RAD ? fmaxf(me.r, 0.0f) : 0.0f) : inf;
     // the tile's bounding box; parked (despawned) pedestrians sit ~3e15 m away, no cull can keep them
     const bool inbox = me.live && fabsf(me.x) < 1.0e12f && fabsf(me.y) < 1.0e12f;
@@ -569,12 +558,11 @@ __device__ __forceinline__ void geometry_block(const TickArgs& a, GeoShared<GW>&
     float f[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
     // ---- phase 1: find
-    const int slice = slice_y;                                      // small crowds: the tile's polylines are split over
-    const int gwave = slice * GW + wave, n_gwaves = GW * n_slices;       // n_slices workgroups
+    const int gwave = slice * GW + wave, n_gwaves = GW * n_slices;       // small crowds: the tile's polylines are split over n_slices workgroups
     const int n_found = geo_find<RAD, false>(a, me, tb, sh.item[wave], row, lane, gwave, n_gwaves, f);
     if (lane == 0) sh.count[wave] = min(n_found, GEO_ITEMS);
     __syncthreads();
-    if (a.geo_stamps) st1 = __builtin_amdgcn_s_memrealtime();
+    if (st1) *st1 = __builtin_amdgcn_s_memrealtime();
 
     // ---- phase 2: scan, items dealt round-robin in (wave, index) order
     {
@@ -598,6 +586,30 @@ __device__ __forceinline__ void geometry_block(const TickArgs& a, GeoShared<GW>&
 #pragma unroll
     for (int q = 0; q < 6; ++q) sh.acc[wave][q][lane] = f[q];
     __syncthreads();
+}
+
+// The border / obstacle forces of tile (a.i_begin / 64 + bx), slice slice_y of n_slices: the body of sfm_geometry_kernel, callable
+// from another kernel's workgroups as well (sfm_pair_geo_kernel).  n_bx only places the diagnostic stamps.
+template <bool RAD, int GW>
+__device__ __forceinline__ void geometry_block(const TickArgs& a, GeoShared<GW>& sh, int bx, int slice_y, int n_slices, int n_bx, int tid) {
+    const int lane = tid & (WAVE - 1);
+    const int wave = uniform((int)(tid >> 6));
+    unsigned long long st0 = 0, st1 = 0, st2 = 0;
+    if (a.geo_stamps) st0 = __builtin_amdgcn_s_memrealtime();
+    const int t = (a.i_begin >> 6) + bx;                      // tile index
+    const int p0 = max(a.i_begin, t * WAVE), p1 = min(a.i_end, (t + 1) * WAVE);
+    const int i = t * WAVE + lane;
+    GeoLane me;
+    me.live = i >= p0 && i < p1;
+    me.x = 3.0e15f; me.y = 3.0e15f; me.vx = 0.f; me.vy = 0.f; me.r = 0.f;
+    if (me.live) {
+        const float4 s = a.pk_cur[i];
+        me.x = s.x; me.y = s.y; me.vx = s.z; me.vy = s.w;
+        me.r = a.own[i].w;
+    }
+    me.walk = me.live && !(a.crossing && a.crossing[i]);              // forces.py:140-141,176-177
+    const int slice = slice_y;
+    geometry_forces<RAD, GW>(a, sh, me, slice, n_slices, tid, a.geo_stamps ? &st1 : nullptr);
     if (a.geo_stamps) st2 = __builtin_amdgcn_s_memrealtime();
     for (int q = wave; q < 6 && me.live; q += GW) {                    // wave w finishes component w (and w + GW)
         float v = 0.0f;
@@ -1904,39 +1916,66 @@ constexpr int GROUP = 2 * WAVE;                  // pedestrians per group of two
 //      arrives from the neighbouring lane and takes this step's term in one instruction).  60 -> 54 issued VALU instructions per step,
 //      the six v_mov_b32_dpp (half rate) among those gone.  Needs wave_rol:1 to hand lane l the value of lane l+1 (probed at init).
 //      (Measured and dropped: the sums in LDS as well, by ds_add_f32 -- LDS float atomics run at ~2 cycles per LANE: 88.8 against 17.5 us.)
-template <bool RAD, int NW, int SYS>             // NW waves per workgroup (8 or 16): 256 / NW systolic steps each
-__global__ __launch_bounds__(NW * WAVE) void sfm_fused_tick_kernel(const TickArgs a, const FusedArgs f) {
+// GEO (round 3): the crowd also feels border / obstacle forces.  Their workgroups are a second ROLE of the same launch -- blocks
+// [0, n_geo_wg): one workgroup per (tile, slice of the polylines); it integrates its tile's group exactly like a pair workgroup
+// does (same code, same bits, nothing stored) and then runs the geometry kernel's body on the new state, leaving ONE float2 per
+// pedestrian and slice in geo_next; every integrating prologue adds the previous launch's geo_prev rows to the force.  Vehicles that
+// move on the device are a third role (blocks behind the pair workgroups, a wave per vehicle): they write the NEXT launch's centres and
+// rings into the other half of a ping-pong while this launch's geometry workgroups read the current one.
+template <bool RAD, int NW, int SYS>
+struct FusedShared {                             // LDS of one pair-role workgroup
+    float4 st[2 * GROUP];                        // the workgroup's pedestrians in the state the pairs are evaluated on: GX then GY
+    float rad[2 * GROUP];
+    float2 q[NW / 2][2 * GROUP];                 // partial column sums
+    float2 part[2 * GROUP];                      // exact rows
+    int badrow[2 * GROUP];
+    int any;
+    float2 fi[NW][WAVE];
+    float2 fj[NW][WAVE];
+    float4 trav[SYS ? 4 : 1][2 * WAVE];          // SYS 1: the four tiles as travelling operands, each twice back to back
+    float radt[(SYS && RAD) ? 4 : 1][2 * WAVE];
+};
+
+template <bool RAD, int NW, int SYS, bool GEO>   // NW waves per workgroup (8 or 16): 256 / NW systolic steps each
+__global__ __launch_bounds__(NW * WAVE, 8) void sfm_fused_tick_kernel(const TickArgs a, const FusedArgs f) {   // 8 waves per SIMD: two 16-wave (four 8-wave) workgroups per CU
     constexpr int PARTS = NW / 2;                // the slab rows are split over this many 128-thread parts
     constexpr int SPW = 4 * WAVE / NW;           // systolic steps per wave
     constexpr int D = NW / 8;                    // waves per diagonal tile
-    __shared__ float4 s_st[2 * GROUP];           // the workgroup's pedestrians in the state the pairs are evaluated on: GX then GY
-    __shared__ float s_rad[2 * GROUP];
-    __shared__ float2 s_q[PARTS][2 * GROUP];     // partial column sums
-    __shared__ float2 s_part[2 * GROUP];         // exact rows
-    __shared__ int s_badrow[2 * GROUP];
-    __shared__ int s_any;
-    __shared__ float2 s_fi[NW][WAVE];
-    __shared__ float2 s_fj[NW][WAVE];
-    __shared__ float4 s_trav[SYS ? 4 : 1][2 * WAVE];   // SYS 1: the four tiles as travelling operands, each twice back to back
-    __shared__ float s_radt[(SYS && RAD) ? 4 : 1][2 * WAVE];
+    using Sh = FusedShared<RAD, NW, SYS>;
+    constexpr size_t LDS = (GEO && sizeof(GeoShared<NW>) > sizeof(Sh)) ? sizeof(GeoShared<NW>) : sizeof(Sh);
+    __shared__ __attribute__((aligned(16))) char smem[LDS];
+    Sh& sh = *reinterpret_cast<Sh*>(smem);
     const int tid = threadIdx.x;
     const int lane = tid & (WAVE - 1);
     const int wave = uniform(tid >> 6);
     const int n_g = f.n_g, n_t = f.n_t;
     const int half_up = (n_g + 1) >> 1;          // diagonal items pair group bx with group bx + half_up
+    // roles: [0, n_geo_wg) border / obstacle forces of one (tile, slice); then the pair workgroups; then the vehicles
+    const bool geo_role = GEO && (int)blockIdx.x < f.n_geo_wg;
+    const int bid = (int)blockIdx.x - (GEO ? f.n_geo_wg : 0);
+    if (GEO && bid >= f.n_pair_wg) {                                   // the vehicles move on: V(in) -> V(out), a wave each
+        const int k = (bid - f.n_pair_wg) * NW + wave;
+        if (k < a.adv.M) advance_vehicle(a.adv, k, lane, true);
+        return;
+    }
+    const int geo_tile = geo_role ? (int)blockIdx.x % n_t : 0, geo_slice = geo_role ? (int)blockIdx.x / n_t : 0;
     // Work items, one per workgroup and no idle workgroup in the grid (the dispatcher deals workgroup w to CU w mod 256 whatever
     // it holds, so a grid with holes leaves some CUs a whole workgroup more than others).
     int GX, GY;
     bool diag_item;
-    if (f.blocked) {
+    if (geo_role) {
+        // a geometry workgroup integrates the GROUP of its tile as a pair workgroup would (GY absent, nothing stored)
+        GX = geo_tile >> 1; GY = n_g;
+        diag_item = false;
+    } else if (f.blocked) {
         // n_g a multiple of 8: the groups go in four bands of s, and the workgroups that land on one XCD (w mod 8, observed on
         // MI355X; nothing but speed depends on it) take their group pairs from one pair of bands -- XCDs 0-5 the six pairs of
         // different bands (s x s workgroups each), XCDs 6 and 7 two bands' inner pairs each (s/2 diagonal items of neighbouring
         // groups + s (s-1) / 2 pairs per band = s x s for two bands).  An XCD's L2 then fetches the column sums of 2 s groups
         // instead of all 4 s: half the traffic across the fabric at the start of the launch.
         const int s = n_g >> 2;
-        const int x = blockIdx.x & 7;
-        int k = blockIdx.x >> 3;
+        const int x = bid & 7;
+        int k = bid >> 3;
         if (x < 6) {
             const int I = x < 3 ? 0 : (x < 5 ? 1 : 2), J = x < 3 ? x + 1 : (x < 5 ? x - 1 : 3);
             GX = I * s + k / s;
@@ -1959,7 +1998,7 @@ __global__ __launch_bounds__(NW * WAVE) void sfm_fused_tick_kernel(const TickArg
     } else {
         // first the diagonal items (group bx with group bx + half_up), then the group pairs (bx, bx + shift) shift by shift; the
         // last shift of an even n_g (antipodal pairs) has only its lower half
-        int shift = 0, bx = blockIdx.x;
+        int shift = 0, bx = bid;
         if (bx >= half_up) {
             const int id = bx - half_up;
             shift = 1 + id / n_g;
@@ -1983,28 +2022,33 @@ __global__ __launch_bounds__(NW * WAVE) void sfm_fused_tick_kernel(const TickArg
     const int i = G * GROUP + (p & (GROUP - 1)); // < N_pad whenever the group exists (N_pad is a multiple of four tiles)
     const bool live = present && i < a.N;
     float4 st = make_float4(0.f, 0.f, 0.f, 0.f), o = st;
+    float2 geo_f = make_float2(0.f, 0.f);        // GEO: border + obstacle forces on the stored state, left by the previous launch
     uint32_t nd0 = 0, pid = 0;
     if (present && lower) {
         st = a.pk_cur[i];
         if (live && integrate) {
             o = f.own_cur[i];
+            if (GEO) {
+                float2 gv[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) gv[k] = k < f.geo_slices ? f.geo_prev[(size_t)k * a.N_pad + i] : make_float2(0.f, 0.f);
+                geo_f = make_float2((gv[0].x + gv[1].x) + (gv[2].x + gv[3].x), (gv[0].y + gv[1].y) + (gv[2].y + gv[3].y));
+            }
             if ((a.flags & 2u) && diag_item) { nd0 = a.draws[i]; pid = a.ids ? a.ids[i] : (uint32_t)i; }
         }
         if (RAD) {
             const float r_ = a.radius[i];
-            s_rad[p] = r_;
-            if (SYS) { s_radt[(SYS && RAD) ? (p >> 6) : 0][p & (WAVE - 1)] = r_; s_radt[(SYS && RAD) ? (p >> 6) : 0][(p & (WAVE - 1)) + WAVE] = r_; }
+            sh.rad[p] = r_;
+            if (SYS) { sh.radt[(SYS && RAD) ? (p >> 6) : 0][p & (WAVE - 1)] = r_; sh.radt[(SYS && RAD) ? (p >> 6) : 0][(p & (WAVE - 1)) + WAVE] = r_; }
         }
     }
-    if (tid == 0) s_any = 0;
+    if (tid == 0) sh.any = 0;
     {
         const int pp = tid & (GROUP - 1);        // pedestrians 2 pp, 2 pp + 1 of the workgroup's 256
         const int part = uniform(tid >> 7);
         const int Gq = (2 * pp < GROUP) ? GX : GY;
         const int i2 = Gq * GROUP + ((2 * pp) & (GROUP - 1));
         float4 acc4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (f.stagger > 0 && integrate && blockIdx.x >= 256u)
-            for (int k = 0; k < f.stagger; ++k) __builtin_amdgcn_s_sleep(8);
         if (integrate && a.en_ped && Gq < n_g && i2 < a.N) {
             const float4* col = reinterpret_cast<const float4*>(f.slab_prev + i2);
             const size_t stride4 = (size_t)a.N_pad / 2;
@@ -2020,18 +2064,18 @@ __global__ __launch_bounds__(NW * WAVE) void sfm_fused_tick_kernel(const TickArg
                 acc4.w += ((v[0].w + v[1].w) + (v[2].w + v[3].w)) + ((v[4].w + v[5].w) + (v[6].w + v[7].w));
             }
         }
-        s_q[part][2 * pp] = make_float2(acc4.x, acc4.y);
-        s_q[part][2 * pp + 1] = make_float2(acc4.z, acc4.w);
+        sh.q[part][2 * pp] = make_float2(acc4.x, acc4.y);
+        sh.q[part][2 * pp + 1] = make_float2(acc4.z, acc4.w);
     }
     __syncthreads();
     // the arithmetic of sfm_sym_epilogue_kernel without border / obstacle forces (pedestrian_simulation.py:57-83,
     // forces.py:40-52): acceleration towards the waypoint, capped velocity, position, arrival -> next waypoint
     auto put_state = [&](const float4 ns) {       // pedestrian slot p of the workgroup in the state the pairs are evaluated on
-        s_st[p] = ns;
+        sh.st[p] = ns;
         if (SYS) {
             const float4 t = make_float4(ns.x, ns.y, a.ped.lam * ns.z, a.ped.lam * ns.w);
-            s_trav[p >> 6][p & (WAVE - 1)] = t;
-            s_trav[p >> 6][(p & (WAVE - 1)) + WAVE] = t;
+            sh.trav[p >> 6][p & (WAVE - 1)] = t;
+            sh.trav[p >> 6][(p & (WAVE - 1)) + WAVE] = t;
         }
     };
     auto finish = [&](const float2 g) {
@@ -2046,7 +2090,7 @@ __global__ __launch_bounds__(NW * WAVE) void sfm_fused_tick_kernel(const TickArg
             fax = (ts * (tx_ * inv) - vx) * a.inv_tau;
             fay = (ts * (ty_ * inv) - vy) * a.inv_tau;
         }
-        const float Fx = fax + fpx, Fy = fay + fpy;
+        const float Fx = (fax + fpx) + geo_f.x, Fy = (fay + fpy) + geo_f.y;   // forces.py order: acceleration, pedestrian, border + obstacles
         float nvx = fmaf(a.dt, Fx, vx), nvy = fmaf(a.dt, Fy, vy);
         float sp = sqrtf(fmaf(nvx, nvx, nvy * nvy));
         sp = (sp == 0.0f) ? 1.0f : sp;
@@ -2073,23 +2117,23 @@ __global__ __launch_bounds__(NW * WAVE) void sfm_fused_tick_kernel(const TickArg
     bool bad = false;
     if (lower && present) {
         if (integrate && live) {
-            float2 g = s_q[0][p];
+            float2 g = sh.q[0][p];
 #pragma unroll
-            for (int k = 1; k < PARTS; ++k) { const float2 q = s_q[k][p]; g.x += q.x; g.y += q.y; }
+            for (int k = 1; k < PARTS; ++k) { const float2 q = sh.q[k][p]; g.x += q.x; g.y += q.y; }
             bad = a.en_ped && (!(fabsf(g.x) < __builtin_inff()) || !(fabsf(g.y) < __builtin_inff()));
-            if (bad) s_any = 1; else finish(g);
+            if (bad) sh.any = 1; else finish(g);
         } else {
             put_state(st);                                           // ghosts, and the first launch of a run: as stored
         }
     }
-    if (lower) s_badrow[p] = bad ? 1 : 0;
+    if (lower) sh.badrow[p] = bad ? 1 : 0;
     __syncthreads();
-    if (s_any) {
+    if (sh.any) {
         // coincident pairs: the rows that caught a NaN are recomputed with the exact ordered body (rare; every workgroup that
         // holds such a row does it, and they all get the same bits)
         const int N = a.N;
         for (int q = wave; q < 2 * GROUP; q += NW) {
-            if (!s_badrow[q]) continue;                                  // uniform
+            if (!sh.badrow[q]) continue;                                  // uniform
             const int Gq = (q < GROUP) ? GX : GY;
             const int ip = Gq * GROUP + (q & (GROUP - 1));
             const float4 si = a.pk_cur[ip];
@@ -2107,11 +2151,32 @@ __global__ __launch_bounds__(NW * WAVE) void sfm_fused_tick_kernel(const TickArg
             }
             gx = wave_sum(gx);
             gy = wave_sum(gy);
-            if (lane == 0) s_part[q] = make_float2(gx, gy);
+            if (lane == 0) sh.part[q] = make_float2(gx, gy);
         }
         __syncthreads();
-        if (bad) finish(s_part[p]);
+        if (bad) finish(sh.part[p]);
         __syncthreads();
+    }
+
+    if (GEO && geo_role) {
+        // ---- 2g. border / obstacle forces on the new state of tile geo_tile (the geometry kernel's body), one float2 per pedestrian
+        const int ig = geo_tile * WAVE + lane;
+        const float4 sg = sh.st[(geo_tile & 1) * WAVE + lane];
+        GeoLane me;
+        me.live = ig < a.N;
+        me.x = 3.0e15f; me.y = 3.0e15f; me.vx = 0.f; me.vy = 0.f; me.r = 0.f;
+        if (me.live) { me.x = sg.x; me.y = sg.y; me.vx = sg.z; me.vy = sg.w; me.r = f.own_cur[ig].w; }
+        me.walk = me.live && !(a.crossing && a.crossing[ig]);          // forces.py:140-141,176-177
+        __syncthreads();                                               // the geometry body's LDS lies over the prologue's
+        GeoShared<NW>& gs = *reinterpret_cast<GeoShared<NW>*>(smem);
+        geometry_forces<RAD, NW>(a, gs, me, geo_slice, f.geo_slices, tid, nullptr);
+        if (wave < 2 && me.live) {                                     // wave 0: x, wave 1: y -- border, static, dynamic in that order
+            float vb = 0.f, vs = 0.f, vd = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) { vb += gs.acc[w][wave][lane]; vs += gs.acc[w][2 + wave][lane]; vd += gs.acc[w][4 + wave][lane]; }
+            reinterpret_cast<float*>(f.geo_next + (size_t)geo_slice * a.N_pad + ig)[wave] = (vb + a.stat.negA * vs) + a.dyn.negA * vd;
+        }
+        return;
     }
 
     // ---- 2. this workgroup's tile pairs on the new state: every wave SPW systolic steps (sfm_pair_sym_kernel's step)
@@ -2144,13 +2209,13 @@ __global__ __launch_bounds__(NW * WAVE) void sfm_fused_tick_kernel(const TickArg
     int i_end_loc = lane;
     if (work && SYS) {
         const IxConst& c = a.ped;
-        const float4 pj = s_st[ib + lane];
+        const float4 pj = sh.st[ib + lane];
         const float ujx = c.lam * pj.z, ujy = c.lam * pj.w;
         float rj = 0.f;
-        if (RAD) rj = s_rad[ib + lane];
+        if (RAD) rj = sh.rad[ib + lane];
         // step s meets pedestrian (lane + sig0 + s) mod 64 of the travelling tile: slot lane + sig0 + s of the doubled image
-        const float4* trav = &s_trav[SYS ? (ia >> 6) : 0][lane + sig0];
-        const float* radt = &s_radt[(SYS && RAD) ? (ia >> 6) : 0][lane + sig0];
+        const float4* trav = &sh.trav[SYS ? (ia >> 6) : 0][lane + sig0];
+        const float* radt = &sh.radt[(SYS && RAD) ? (ia >> 6) : 0][lane + sig0];
         // sigma = 32 on a diagonal tile meets every unordered pair {l, l+32} in BOTH lanes: one-sided there
         const bool tail_one_sided = diag && (sig0 + SPW - 1 == 32);  // uniform
         float4 T = trav[0];
@@ -2176,11 +2241,11 @@ __global__ __launch_bounds__(NW * WAVE) void sfm_fused_tick_kernel(const TickArg
         i_end_loc = (lane + sig0 + SPW - 1) & (WAVE - 1);
     }
     if (work && !SYS) {
-        const float4 pj = s_st[ib + lane];
+        const float4 pj = sh.st[ib + lane];
         const int i_loc0 = (lane + f.dir * sig0) & (WAVE - 1);
-        const float4 pi0 = s_st[ia + i_loc0];
+        const float4 pi0 = sh.st[ia + i_loc0];
         float rj = 0.f, ri = 0.f;
-        if (RAD) { rj = s_rad[ib + lane]; ri = s_rad[ia + i_loc0]; }
+        if (RAD) { rj = sh.rad[ib + lane]; ri = sh.rad[ia + i_loc0]; }
         const IxConst& c = a.ped;
         float xi = pi0.x, yi = pi0.y, uxi = c.lam * pi0.z, uyi = c.lam * pi0.w;
         const float ujx = c.lam * pj.z, ujy = c.lam * pj.w;
@@ -2203,24 +2268,24 @@ __global__ __launch_bounds__(NW * WAVE) void sfm_fused_tick_kernel(const TickArg
         if (tail_one_sided) step(false); else step(true);
         i_end_loc = (lane + f.dir * (sig0 + SPW)) & (WAVE - 1);
     }
-    s_fi[wave][i_end_loc] = make_float2(fxi, fyi);
-    s_fj[wave][lane] = make_float2(fxj, fyj);
+    sh.fi[wave][i_end_loc] = make_float2(fxi, fyi);
+    sh.fj[wave][lane] = make_float2(fxj, fyj);
     __syncthreads();
     if (!lower || !present) return;
     const int tl = (p >> 6) & 1, l = lane;       // tile of the group, pedestrian of the tile
-    auto fi = [&](int w) { return s_fi[w][l]; };   // travelling-side sum of wave w for pedestrian l of its travelling tile
+    auto fi = [&](int w) { return sh.fi[w][l]; };   // travelling-side sum of wave w for pedestrian l of its travelling tile
     float2 r = make_float2(0.f, 0.f);
     int row;                                     // partner group = slab row
     if (diag_item) {
         const int w0 = (p < GROUP) ? 0 : NW / 2;
 #pragma unroll
         for (int k = 0; k < D; ++k) {            // the tile's own diagonal item: both sides are this tile
-            const float2 u = fi(w0 + tl * D + k), v = s_fj[w0 + tl * D + k][l];
+            const float2 u = fi(w0 + tl * D + k), v = sh.fj[w0 + tl * D + k][l];
             r.x += u.x + v.x; r.y += u.y + v.y;
         }
 #pragma unroll
         for (int k = 0; k < 2 * D; ++k) {        // the other tile of the group
-            const float2 u = tl ? s_fj[w0 + 2 * D + k][l] : fi(w0 + 2 * D + k);
+            const float2 u = tl ? sh.fj[w0 + 2 * D + k][l] : fi(w0 + 2 * D + k);
             r.x += u.x; r.y += u.y;
         }
         row = G;
@@ -2232,7 +2297,7 @@ __global__ __launch_bounds__(NW * WAVE) void sfm_fused_tick_kernel(const TickArg
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int k = 0; k < NW / 4; ++k) { const float2 u = s_fj[(2 * h + tl) * (NW / 4) + k][l]; r.x += u.x; r.y += u.y; }
+            for (int k = 0; k < NW / 4; ++k) { const float2 u = sh.fj[(2 * h + tl) * (NW / 4) + k][l]; r.x += u.x; r.y += u.y; }
         row = GX;
     }
     f.slab_next[(size_t)row * a.N_pad + i] = r;
@@ -2245,7 +2310,7 @@ __global__ __launch_bounds__(BLOCK) void sfm_dynamic_boxes_kernel(float4* __rest
                                                                   float2* __restrict__ pts, int M, float dt, int advance) {
     const int k = blockIdx.x * WAVES_PER_BLOCK + (int)(threadIdx.x >> 6);
     if (k >= M) return;
-    advance_vehicle(DynAdvance{ctr, off, local, rot, pts, M, dt, 0}, k, threadIdx.x & (WAVE - 1), advance != 0);
+    advance_vehicle(DynAdvance{ctr, off, local, rot, pts, M, dt, 0, nullptr, nullptr}, k, threadIdx.x & (WAVE - 1), advance != 0);
 }
 
 // get_arrived_peds (pedestrian_simulation.py:88-97) on the current device state.
@@ -2434,19 +2499,26 @@ hipError_t launch_sym_epilogue(bool rad, const TickArgs& a, const SymArgs& sa, h
 }
 
 // one launch of the fused tick (FusedArgs::mode)
+// number of pair workgroups of the fused tick: diagonal items, full shifts, the half shift of an even n_g
+int fused_pair_workgroups(int n_g) { return (n_g + 1) / 2 + n_g * ((n_g - 1) / 2) + ((n_g & 1) ? 0 : n_g / 2); }
+
+template <bool RAD, int NW, int SYS>
+static void launch_fused_t(dim3 grid, bool geo, const TickArgs& a, const FusedArgs& f, hipStream_t st) {
+    if (geo) hipLaunchKernelGGL((sfm_fused_tick_kernel<RAD, NW, SYS, true>), grid, dim3(NW * WAVE), 0, st, a, f);
+    else hipLaunchKernelGGL((sfm_fused_tick_kernel<RAD, NW, SYS, false>), grid, dim3(NW * WAVE), 0, st, a, f);
+}
+
 hipError_t launch_fused_tick(bool rad, const TickArgs& a, const FusedArgs& f, hipStream_t st, int nw, int sys) {
     if (a.N <= 1 || f.n_g < 2) return hipErrorInvalidValue;
-    const int n_g = f.n_g, diag = (n_g + 1) / 2;            // diagonal items, full shifts, the half shift of an even n_g
-    const dim3 grid(diag + n_g * ((n_g - 1) / 2) + ((n_g & 1) ? 0 : n_g / 2));
+    const bool geo = f.n_geo_wg > 0;
+    const int n_adv = (geo && a.adv.M > 0) ? (a.adv.M + nw - 1) / nw : 0;
+    const dim3 grid(f.n_geo_wg + f.n_pair_wg + n_adv);
     if (nw == 8) {
-        if (rad) hipLaunchKernelGGL((sfm_fused_tick_kernel<true, 8, 0>), grid, dim3(8 * WAVE), 0, st, a, f);
-        else hipLaunchKernelGGL((sfm_fused_tick_kernel<false, 8, 0>), grid, dim3(8 * WAVE), 0, st, a, f);
-    } else if (sys == 0) {
-        if (rad) hipLaunchKernelGGL((sfm_fused_tick_kernel<true, 16, 0>), grid, dim3(16 * WAVE), 0, st, a, f);
-        else hipLaunchKernelGGL((sfm_fused_tick_kernel<false, 16, 0>), grid, dim3(16 * WAVE), 0, st, a, f);
+        if (sys == 0) { if (rad) launch_fused_t<true, 8, 0>(grid, geo, a, f, st); else launch_fused_t<false, 8, 0>(grid, geo, a, f, st); }
+        else { if (rad) launch_fused_t<true, 8, 1>(grid, geo, a, f, st); else launch_fused_t<false, 8, 1>(grid, geo, a, f, st); }
     } else {
-        if (rad) hipLaunchKernelGGL((sfm_fused_tick_kernel<true, 16, 1>), grid, dim3(16 * WAVE), 0, st, a, f);
-        else hipLaunchKernelGGL((sfm_fused_tick_kernel<false, 16, 1>), grid, dim3(16 * WAVE), 0, st, a, f);
+        if (sys == 0) { if (rad) launch_fused_t<true, 16, 0>(grid, geo, a, f, st); else launch_fused_t<false, 16, 0>(grid, geo, a, f, st); }
+        else { if (rad) launch_fused_t<true, 16, 1>(grid, geo, a, f, st); else launch_fused_t<false, 16, 1>(grid, geo, a, f, st); }
     }
     return hipGetLastError();
 }

@@ -817,6 +817,99 @@ def test_fused_tick_pinned_to_the_oracle_at_c2(monkeypatch):
         eng.close()
 
 
+def _geo_scenario(n, seed):
+    """A mid-sized crowd with all five forces: borders, static obstacles, vehicles that move on the device."""
+    return scenarios.make_scenario(n, seed, n_borders=max(24, n // 16), n_static=max(12, n // 128), n_dynamic=6, border_len=(5.0, 25.0))
+
+
+def _geo_engine(sc, cfg):
+    eng = SfmEngine(cfg, 0.05)
+    eng.set_borders(sc.borders, sc.border_centers, sc.border_lengths)
+    eng.set_static_obstacles(sc.static_obstacles)
+    eng.set_dynamic_boxes([c for c, _ in sc.dynamic_obstacles], sc.dynamic_yaw, sc.dynamic_extent, sc.dynamic_vel)
+    eng.upload_state(sc.loc, sc.vel, sc.waypoint, sc.target_speed, sc.radius, None)
+    eng.set_waypoint_stream(sc.seed, sc.world_side, 2.0)
+    return eng
+
+
+@pytest.mark.parametrize("n", [512, 1000, 2048, 4096])
+def test_fused_tick_with_border_and_obstacle_forces_pinned_to_the_oracle(n, monkeypatch):
+    """Round 3: crowds below the list cutoff WITH border / obstacle forces take the fused tick too -- geometry workgroups are a
+    second role of sfm_fused_tick_kernel, vehicles that move on the device a third (forces.py:138-283, obstacles.py:297-329).
+    Every tick re-synchronised against the oracle (v' 1e-5, x' 1e-6), the device's vehicles against the host twin bit for bit;
+    N = 4096 runs the 8-wave form of the launch (pair + geometry workgroups do not fit in 512 slots of 16 waves)."""
+    sc = _geo_scenario(n, 6100 + n)
+    cfg = default_sfm_config(scenarios.ALL_FORCES)
+    prm = O.OracleParams.from_config(cfg)
+    monkeypatch.setenv("SFM_FUSED", "2")                      # a single sfm_run(1) takes the fused tick (launch in front + one integrating launch)
+    eng = _geo_engine(sc, cfg)
+    try:
+        loc, vel, wp = sc.loc.copy(), sc.vel.copy(), sc.waypoint.copy()
+        crossing = np.zeros(n, bool)
+        blocks = ((0, n),) if n <= 1000 else ((0, 128), (n // 2 - 64, n // 2 + 64), (n - 128, n))
+        worst = 0.0
+        for k in range(6):
+            for (c_d, r_d), (c_h, r_h) in zip(eng.dynamic_obstacles(), sc.dynamic_obstacles):
+                assert np.array_equal(c_d, c_h) and np.array_equal(r_d, r_h), f"vehicles at tick {k}"
+            geom = O.Geometry(sc.borders, sc.border_centers, sc.border_lengths, sc.static_obstacles, sc.dynamic_obstacles, sc.dynamic_vel)
+            eng.run(1, redraw=True)
+            assert "fused_tick_kernel(geo)" in eng.kernel_variant(), eng.kernel_variant()
+            dloc, dvel, dwp = eng.state()
+            for r in blocks:
+                with np.errstate(all="ignore"):
+                    _, _, v_new, expo, absum = c_oracle.tick(loc, vel, wp, sc.target_speed, sc.radius, crossing, geom, prm, 0.05, rows=r,
+                                                             theta_tol=P.THETA_TOL)
+                sl = slice(r[0], r[1])
+                P.check_velocity_conditioned(dvel[sl], v_new, expo, absum, 0.05)
+                worst = max(worst, float(np.max(np.linalg.norm(dvel[sl] - v_new, axis=1) / np.maximum(np.linalg.norm(v_new, axis=1), 1e-12))))
+                x_new = loc[sl] + 0.05 * v_new
+                x_new[:, 2] = loc[sl, 2]
+                allow = 1e-6 * np.maximum(1.0, np.abs(x_new).max(axis=1)) + 0.05 * (1e-5 * 0.05 * absum + 0.05 * expo * 1.001)
+                assert (np.abs(dloc[sl] - x_new).max(axis=1) <= allow).all(), f"x' at tick {k}"
+            loc, vel = dloc, dvel
+            wp = np.concatenate([dwp, np.zeros((n, 1))], axis=1)
+            scenarios.advance_dynamic(sc, 0.05)
+        print(f"\nfused tick with geometry vs oracle, N={n}: {eng.kernel_variant()}  worst |dv'|/|v'| {worst:.3g}")
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("n,use_radius", [(700, False), (2500, True), (4096, False)])
+def test_fused_run_with_border_and_obstacle_forces_matches_the_two_launch_tick(n, use_radius, monkeypatch):
+    """The CARRIED path of the same: inside one sfm_run the geometry workgroups of launch k evaluate the state launch k has just
+    integrated, against the vehicles launch k-1 moved on (ping-pong), across device re-packs (every 5 ticks here: each followed by a
+    launch in front).  14 ticks agree with the two-launch tick (pair + geometry launch, epilogue launch) to rounding drift, the
+    vehicles end in the same place bit for bit, two runs are bit-identical, and split runs carry on."""
+    sc = _geo_scenario(n, 7300 + n)
+    cfg = default_sfm_config(scenarios.ALL_FORCES)
+    cfg["use_ped_radius"] = use_radius
+    monkeypatch.setenv("SFM_RESORT_EVERY", "5")
+    out = {}
+    for tag, env in (("fused", "1"), ("again", "1"), ("split", "1"), ("two-launch", "0")):
+        monkeypatch.setenv("SFM_FUSED_GEO", env)
+        eng = _geo_engine(sc, cfg)
+        try:
+            if tag == "split":
+                eng.run(6, redraw=True); eng.run(1, redraw=True); eng.run(7, redraw=True)      # carried on (nothing in between)
+            else:
+                eng.run(14, redraw=True)
+            assert ("fused" in eng.kernel_variant()) == (env == "1"), eng.kernel_variant()
+            out[tag] = eng.state() + (eng.draw_counts(), np.concatenate([np.concatenate([c, r.ravel()]) for c, r in eng.dynamic_obstacles()]))
+        finally:
+            eng.close()
+    for a, b in zip(out["fused"], out["again"]):
+        assert np.array_equal(a, b, equal_nan=True)
+    for a, b in zip(out["fused"], out["split"]):
+        assert np.array_equal(a, b, equal_nan=True)
+    assert np.array_equal(out["fused"][4], out["two-launch"][4])              # the vehicles
+    loc, vel = out["fused"][:2]
+    loc0, vel0 = out["two-launch"][:2]
+    assert np.isfinite(loc).all() and np.isfinite(vel).all()
+    dev = max(np.abs(loc - loc0).max(), np.abs(vel - vel0).max())
+    print(f"\nfused (geo) vs two-launch tick, N={n}: max deviation after 14 ticks {dev:.3g}")
+    assert dev < 5e-4, dev                                                    # drift bound (a missing force or tile shows as 1e-2 and more)
+
+
 @pytest.mark.parametrize("waves,blocked", [("8", "1"), ("16", "0")])
 def test_fused_tick_variants_and_pedestrian_force_alone(waves, blocked, monkeypatch):
     """The fused tick's A/B variants (8-wave workgroups; the plain order of the work items where the XCD-aware one applies) and a
