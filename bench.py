@@ -21,7 +21,7 @@ Workloads (--workload overrides the default, and the SAME 
             re-pack on every rank each 64 ticks.  Rank 0 first times the SAME workload on ONE GPU with the same
             protocol ("single_gpu_same_workload"), so the strong-scaling speed-up is on the line;
             `--gpus 1 --workload c5` prints that N = 1 point as a line of its own.
-  SFM_BENCH_REHEARSAL=1 (development only): every rank on cuda:0, collectives over gloo -- runs the multi-rank flow end to
+  --rehearsal (development only): every rank on cuda:0, collectives over gloo -- runs the multi-rank flow end to
             end on a one-GPU box; its timings mean nothing.
 
 Roofline record.  The dominant kernel is the pedestrian-pair kernel.  Its binding resource is VALU issue (DESIGN.md
@@ -214,6 +214,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-ref", action="store_true", help="G > 1: skip the one-GPU run of the same workload")
     ap.add_argument("--cpu-budget", type=float, default=10.0)
+    ap.add_argument("--rehearsal", action="store_true", help="development: all ranks on cuda:0, collectives over gloo (timings mean nothing)")
     args = ap.parse_args()
     # stdout carries exactly ONE line, the JSON record: libraries that print at start-up (RCCL: "Librccl path ...", gloo's rank
     # banner in rehearsals) write to file descriptor 1 from C, so it is pointed at stderr for the run and the record goes to a
@@ -236,9 +237,9 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
-    # rehearsal on a one-GPU box (never used by the driver): SFM_BENCH_REHEARSAL=1 puts every rank on cuda:0 and moves the
+    # rehearsal on a one-GPU box (never used by the driver): --rehearsal puts every rank on cuda:0 and moves the
     # collectives over gloo, so that the multi-rank flow (shards, exchange, re-pack protocol) runs end to end
-    rehearsal = os.environ.get("SFM_BENCH_REHEARSAL") == "1"
+    rehearsal = args.rehearsal
     if rehearsal:
         local = 0
     torch.cuda.set_device(local)

@@ -277,6 +277,19 @@ static IxConst fold(const SfmInteraction& s) {
     return c;
 }
 
+// Environment knobs.  The product build reads eleven (SFM_SYM, SFM_IPW, SFM_TEAM, SFM_CUTOFF, SFM_REORDER,
+// SFM_RESORT_EVERY, SFM_FUSED, SFM_STRIPS, SFM_PAIR_GEO, SFM_GEO_SLICES, SFM_NO_STRAIGHT -- each selects a SHIPPING path the tests must be able to
+// reach at a small size).  Everything else -- A/B arrangements measured and dropped, diagnostic stamps, timing probes -- only exists
+// in a build with -DSFM_EXPERIMENTS (make EXPERIMENTS=1).
+static inline const char* exp_env(const char* name) {
+#ifdef SFM_EXPERIMENTS
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
+
 static int check_params(const SfmParams* p, const char** why) {
     if (!p) { *why = "params is NULL"; return 0; }
     if (!(p->step_length > 0.f)) { *why = "step_length must be > 0"; return 0; }
@@ -314,7 +327,7 @@ int sfm_create(const SfmParams* params, int device_id, SfmHandle** out) {
         h->aux = nullptr;
         h->overlap_geo = false;
     }
-    if (getenv("SFM_NO_OVERLAP")) h->overlap_geo = false;
+    if (exp_env("SFM_NO_OVERLAP")) h->overlap_geo = false;
     const char* ov = getenv("SFM_IPW");
     if (ov) h->ipw_override = atoi(ov);
     ov = getenv("SFM_TEAM");
@@ -323,29 +336,29 @@ int sfm_create(const SfmParams* params, int device_id, SfmHandle** out) {
     if (ov) h->sym_mode = atoi(ov);
     ov = getenv("SFM_CUTOFF");
     if (ov) h->cut_mode = atoi(ov);
-    ov = getenv("SFM_CARRY");
+    ov = exp_env("SFM_CARRY");
     if (ov) h->carry_mode = atoi(ov);
-    ov = getenv("SFM_SPLIT");
+    ov = exp_env("SFM_SPLIT");
     if (ov) h->split_mode = atoi(ov);
-    ov = getenv("SFM_GEO_AHEAD");
+    ov = exp_env("SFM_GEO_AHEAD");
     if (ov) h->geo_ahead_mode = atoi(ov);
     ov = getenv("SFM_PAIR_GEO");
     if (ov) h->pair_geo_mode = atoi(ov);
-    ov = getenv("SFM_LIST_MERGE");
+    ov = exp_env("SFM_LIST_MERGE");
     if (ov) h->list_merge_mode = atoi(ov);
     ov = getenv("SFM_FUSED");
     if (ov) h->fused_mode = atoi(ov);
-    ov = getenv("SFM_FUSED_WAVES");
+    ov = exp_env("SFM_FUSED_WAVES");
     if (ov && atoi(ov) == 8) h->fused_waves = 8;
-    ov = getenv("SFM_FUSED_BLOCKED");
+    ov = exp_env("SFM_FUSED_BLOCKED");
     if (ov) h->fused_blocked = atoi(ov);
-    ov = getenv("SFM_FUSED_SYS");
+    ov = exp_env("SFM_FUSED_SYS");
     if (ov) h->fused_sys = atoi(ov);
-    ov = getenv("SFM_FUSED_GEO");
+    ov = exp_env("SFM_FUSED_GEO");
     if (ov) h->fused_geo_mode = atoi(ov);
-    ov = getenv("SFM_FUSED_GEO_SLICES");
+    ov = exp_env("SFM_FUSED_GEO_SLICES");
     if (ov) h->fused_geo_slices = atoi(ov);
-    ov = getenv("SFM_SCHED");
+    ov = exp_env("SFM_SCHED");
     if (ov) h->sched_mode = atoi(ov);
     ov = getenv("SFM_REORDER");
     if (ov) h->reorder_mode = atoi(ov);
@@ -353,18 +366,18 @@ int sfm_create(const SfmParams* params, int device_id, SfmHandle** out) {
     if (ov) h->geo_slices_override = std::min(GEO_SLICES_MAX, std::max(1, atoi(ov)));
     ov = getenv("SFM_STRIPS");
     if (ov) h->strips_override = atoi(ov) != 0 ? 1 : 0;
-    ov = getenv("SFM_DEBUG_STEPS");
+    ov = exp_env("SFM_DEBUG_STEPS");
     if (ov) h->debug_steps = atoi(ov);
     ov = getenv("SFM_RESORT_EVERY");
     if (ov) h->resort_every = atoi(ov);
-    if (getenv("SFM_STAMPS")) {
+    if (exp_env("SFM_STAMPS")) {
         if (hipMalloc(reinterpret_cast<void**>(&h->stamps), sizeof(unsigned long long) * 3 * 8192) != hipSuccess) h->stamps = nullptr;
         else {
-            FILE* f = fopen(getenv("SFM_STAMPS"), "w");   // the address is read back by the diagnostic script through the dump below
+            FILE* f = fopen(exp_env("SFM_STAMPS"), "w");   // the address is read back by the diagnostic script through the dump below
             if (f) fclose(f);
         }
     }
-    if (getenv("SFM_GEO_STAMPS")) {
+    if (exp_env("SFM_GEO_STAMPS")) {
         if (hipMalloc(reinterpret_cast<void**>(&h->geo_stamps), sizeof(unsigned long long) * 4 * 8192) != hipSuccess) h->geo_stamps = nullptr;
         else hipMemset(h->geo_stamps, 0, sizeof(unsigned long long) * 4 * 8192);
     }
@@ -386,18 +399,18 @@ int sfm_destroy(SfmHandle* h) {
     if (!h) return SFM_OK;
     hipSetDevice(h->device);
     hipStreamSynchronize(h->stream);
-    if (h->stamps && getenv("SFM_STAMPS")) {       // diagnostic: dump the last launch's per-workgroup stamps
+    if (h->stamps && exp_env("SFM_STAMPS")) {       // diagnostic: dump the last launch's per-workgroup stamps
         std::vector<unsigned long long> st(3 * 8192);
         if (hipMemcpy(st.data(), h->stamps, sizeof(unsigned long long) * st.size(), hipMemcpyDeviceToHost) == hipSuccess) {
-            FILE* f = fopen(getenv("SFM_STAMPS"), "w");
+            FILE* f = fopen(exp_env("SFM_STAMPS"), "w");
             if (f) { for (size_t b = 0; b < 8192; ++b) fprintf(f, "%llu %llu %llu\n", st[3 * b], st[3 * b + 1], st[3 * b + 2]); fclose(f); }
         }
         hipFree(h->stamps);
     }
-    if (h->geo_stamps && getenv("SFM_GEO_STAMPS")) {   // diagnostic: dump the last launch's per-workgroup phase stamps
+    if (h->geo_stamps && exp_env("SFM_GEO_STAMPS")) {   // diagnostic: dump the last launch's per-workgroup phase stamps
         std::vector<unsigned long long> st(4 * 8192);
         if (hipMemcpy(st.data(), h->geo_stamps, sizeof(unsigned long long) * st.size(), hipMemcpyDeviceToHost) == hipSuccess) {
-            FILE* f = fopen(getenv("SFM_GEO_STAMPS"), "w");
+            FILE* f = fopen(exp_env("SFM_GEO_STAMPS"), "w");
             if (f) { for (size_t b = 0; b < 8192; ++b) fprintf(f, "%llu %llu %llu %llu\n", st[4 * b], st[4 * b + 1], st[4 * b + 2], st[4 * b + 3]); fclose(f); }
         }
         hipFree(h->geo_stamps);
@@ -947,7 +960,12 @@ static void fill_args(SfmHandle* h, TickArgs& a, uint32_t flags) {
     // 128 m square, round 2): the reach of a walking crowd is ~77 m, so only 16 % of the systolic steps are out of reach in the
     // steady state; balanced, the pair kernel drops 15.5 -> 14.9 us while the tile boxes, the dealer and the periodic
     // re-pack add 2.2 us to the tick.  Off by default below 8192 pedestrians.
+#ifdef SFM_EXPERIMENTS
     const bool lite = lite_ok && !cut && h->cut_mode == 2;
+#else
+    const bool lite = false;                       // (the lite cutoff and its dealer: measured, not shipped -- experiments build only)
+    (void)lite_ok;
+#endif
     a.tile_box = (cut || lite) ? h->tile_box + (size_t)h->box_cur * h->n_t : nullptr;
     a.tile_vmax = (cut || lite) ? h->tile_vmax + (size_t)h->box_cur * h->n_t : nullptr;
     // whole crowd on the symmetric path: the epilogue leaves the next tick's boxes (and, list cutoff, a zeroed list counter), so
@@ -1147,7 +1165,7 @@ static int run_fused(SfmHandle* h, int ticks, uint32_t flags, bool carry, bool g
 // 14.3 / 14.0 us per tick at 4 / 8 / 16; N = 2048: 21.0 / 16.4 / 16.4; N = 4096: 27.7 / 23.2 / 24.8 / 26.7 at 2 / 4 / 8 / 16;
 // c3 (256 tiles): 47.3 / 35.2 / 34.9 / 44 at 1 / 2 / 4 / 8; c5: 777 / 781 / 797 at 1 / 2 / 4.
 static int merged_geo_slices(int tiles, int slices) {
-    static const int ov = getenv("SFM_PG_SLICES") ? atoi(getenv("SFM_PG_SLICES")) : 0;      // A/B only
+    static const int ov = exp_env("SFM_PG_SLICES") ? atoi(exp_env("SFM_PG_SLICES")) : 0;      // A/B only
     (void)slices;
     if (ov > 0) return std::min(GEO_SLICES_MAX, ov);
     return tiles >= 1024 ? 1 : tiles >= 64 ? 4 : tiles > 32 ? 8 : 16;
@@ -1178,7 +1196,7 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags, int phase = PHASE_
         order_pays = probe.geo != nullptr || probe.tile_box != nullptr;
         list_cut = probe.tile_box != nullptr && !probe.lite;
         plain = probe.geo == nullptr && probe.tile_box == nullptr && probe.adv.M == 0;
-        fused_geo = probe.geo != nullptr && probe.tile_box == nullptr && h->fused_geo_mode != 0;
+        fused_geo = probe.geo != nullptr && probe.tile_box == nullptr && h->fused_geo_mode != 0;     // (SFM_FUSED=0 switches both off)
     }
     // a shard can use it too when its rows are whole tiles and the tile-pair list is on: pairs with a tile of another
     // rank are then evaluated one-sided by both ranks
@@ -1289,7 +1307,7 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags, int phase = PHASE_
         //  stream (the mirror image -- geometry first on the main stream, list + pair kernel on the side stream -- 53 us).  From
         //  ~1000 tiles on the pair kernel runs for hundreds of microseconds in many rounds of workgroups and the
         //  geometry workgroups do get in between them: c5 825 us in line, 799 us forked.)
-        static const int fork_ov = getenv("SFM_FORK") ? atoi(getenv("SFM_FORK")) : -1;      // A/B only: 0 / 1 = in line / side stream with carried boxes
+        static const int fork_ov = exp_env("SFM_FORK") ? atoi(exp_env("SFM_FORK")) : -1;      // A/B only: 0 / 1 = in line / side stream with carried boxes
         const bool fork_carried = fork_ov >= 0 ? fork_ov == 1 : h->n_t >= 1024;
         // Whole crowd under the list cutoff, boxes and a zeroed list counter carried over: the geometry workgroups go into the pair
         // kernel's launch (sfm_pair_geo_kernel) behind the launch(es) of the list, and overlap with the pair workgroups on the CUs.

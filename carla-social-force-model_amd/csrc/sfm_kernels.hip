@@ -24,6 +24,16 @@
 
 namespace sfm {
 
+// launch-shape A/B knobs exist only in a build with -DSFM_EXPERIMENTS (sfm_capi.hip: exp_env)
+static inline const char* exp_env(const char* name) {
+#ifdef SFM_EXPERIMENTS
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
+
 __device__ __forceinline__ float rsq(float x) { return __builtin_amdgcn_rsqf(x); }
 __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x); }
@@ -2371,7 +2381,7 @@ hipError_t launch_geometry(bool rad, const TickArgs& a, hipStream_t st) {
     const int n_local = a.i_end - a.i_begin;
     if (n_local <= 0) return hipSuccess;
     const int grid = ((a.i_end + WAVE - 1) >> 6) - (a.i_begin >> 6);      // tiles overlapping the shard
-    static const int gw_ov = getenv("SFM_GEO_WAVES") ? atoi(getenv("SFM_GEO_WAVES")) : 0;        // A/B only
+    static const int gw_ov = exp_env("SFM_GEO_WAVES") ? atoi(exp_env("SFM_GEO_WAVES")) : 0;        // A/B only
     const bool thin = gw_ov ? gw_ov == 8 : grid >= 1024;
     TickArgs b = a;
     int extra = 0;                                  // workgroups that build the flat tile-pair list (TickArgs::list_work)
@@ -2412,7 +2422,7 @@ int sym_item_count(int n_t);
 
 template <bool RAD, bool CUT>
 static void launch_sym_pair_t(dim3 grid, const TickArgs& a, const SymArgs& sa, hipStream_t st) {
-    static const int pad_lds = getenv("SFM_PAIR_LDS") ? atoi(getenv("SFM_PAIR_LDS")) : 0;   // experiment: limits the resident workgroups per CU
+    static const int pad_lds = exp_env("SFM_PAIR_LDS") ? atoi(exp_env("SFM_PAIR_LDS")) : 0;   // experiment: limits the resident workgroups per CU
     hipLaunchKernelGGL((sfm_pair_sym_kernel<RAD, CUT>), grid, dim3(BLOCK), (size_t)pad_lds, st, a.pk_cur, a.radius, a.ped, sa);
 }
 
@@ -2423,7 +2433,7 @@ hipError_t launch_sym_pair(bool rad, const TickArgs& a, const SymArgs& sa, hipSt
         // a resident grid takes contiguous runs of the list: a few times more workgroups than fit at once (8 per CU), short runs
         // interleave better with the geometry kernel's workgroups and even out the tail; measured best 4x at 256 tiles, 16x from
         // 1024 tiles on
-        static const int rounds_ov = getenv("SFM_ROUNDS") ? atoi(getenv("SFM_ROUNDS")) : 0;      // A/B only
+        static const int rounds_ov = exp_env("SFM_ROUNDS") ? atoi(exp_env("SFM_ROUNDS")) : 0;      // A/B only
         const int rounds = rounds_ov > 0 ? rounds_ov : std::min(16, std::max(2, sa.n_t / 64));
         grid = sa.cost ? dim3(sym_item_count(sa.n_t)) : dim3(256 * 8 * rounds);    // scheduled: one dealt item per workgroup
     }
@@ -2440,7 +2450,7 @@ hipError_t launch_sym_pair_geo(bool rad, const TickArgs& a, const SymArgs& sa, h
     const int n_geo = tiles * a.geo_slices, n_pair = sa.work ? 256 * 8 * rounds : sa.n_t * (sa.n_t / 2 + 1);
     const dim3 grid(n_geo + n_pair);
     // more geometry workgroups than the CUs hold in one round beside the pair workgroups: spread them evenly over the grid
-    static const int stride_ov = getenv("SFM_PG_STRIDE") ? atoi(getenv("SFM_PG_STRIDE")) : 0;      // A/B only
+    static const int stride_ov = exp_env("SFM_PG_STRIDE") ? atoi(exp_env("SFM_PG_STRIDE")) : 0;      // A/B only
     int stride = n_geo > 256 * 4 ? std::max(1, (n_geo + n_pair) / n_geo) : 1;
     if (stride_ov > 0) stride = std::min(stride_ov, std::max(1, (n_geo + n_pair) / n_geo));
     if (stride > 1 && !(stride & 1)) --stride;      // odd: workgroup w runs on CU w mod 256, an even stride would put every geometry workgroup on a few CUs
@@ -2491,7 +2501,7 @@ static void launch_sym_epilogue_t(const TickArgs& a, const SymArgs& sa, hipStrea
 // mid-sized-crowd feature, needs the 16-wave form).
 hipError_t launch_sym_epilogue(bool rad, const TickArgs& a, const SymArgs& sa, hipStream_t st) {
     if (a.N <= 0) return hipSuccess;
-    static const int ew_ov = getenv("SFM_EPI_WAVES") ? atoi(getenv("SFM_EPI_WAVES")) : 0;      // A/B only: 4 / 16
+    static const int ew_ov = exp_env("SFM_EPI_WAVES") ? atoi(exp_env("SFM_EPI_WAVES")) : 0;      // A/B only: 4 / 16
     const bool thin = (ew_ov ? ew_ov == 4 : sa.n_t >= 1024) && !sa.cost;
     if (rad) { if (thin) launch_sym_epilogue_t<true, 4>(a, sa, st); else launch_sym_epilogue_t<true, EPI_WAVES>(a, sa, st); }
     else { if (thin) launch_sym_epilogue_t<false, 4>(a, sa, st); else launch_sym_epilogue_t<false, EPI_WAVES>(a, sa, st); }

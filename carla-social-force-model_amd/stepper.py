@@ -34,14 +34,13 @@ ROW_COST_TERMS = 600             # HipShardEngine.work(): per-row cost of a tick
 GEOMETRY_ROW_COST_TERMS = 1000   # ... and of the border / obstacle forces
 
 
-def block_layout(world):
+def block_layout(world, layout=None):
     """(gx, gy) of the rank blocks, gx columns by x times gy blocks by y: as square as the rank count allows
-    (2 -> 1x2, 4 -> 2x2, 8 -> 2x4).  SFM_LAYOUT=gx,gy overrides (e.g. "8,1" = the slabs of round 1)."""
-    ov = os.environ.get("SFM_LAYOUT")
-    if ov:
-        gx, gy = (int(v) for v in ov.split(","))
+    (2 -> 1x2, 4 -> 2x2, 8 -> 2x4).  ``layout=(gx, gy)`` overrides (e.g. (8, 1) = the slabs of round 1)."""
+    if layout:
+        gx, gy = (int(v) for v in layout)
         if gx * gy != world:
-            raise ValueError(f"SFM_LAYOUT={ov} does not make {world} blocks")
+            raise ValueError(f"layout {gx}x{gy} does not make {world} blocks")
         return gx, gy
     gy = 1
     while gy * gy * 2 <= world and world % (gy * 2) == 0:
@@ -216,10 +215,10 @@ class ShardedStepper:
     boundaries move so that every rank carries the same pair work (``balanced_bounds``; the measure is the engine's
     ``work()``, all-gathered, so every rank computes the same new boundaries)."""
 
-    def __init__(self, engine, scenario, rank=0, world=1, group=None, redraw=True, resort_every=None, balance=None):
+    def __init__(self, engine, scenario, rank=0, world=1, group=None, redraw=True, resort_every=None, balance=True, layout=None):
         self.engine, self.rank, self.world, self.group, self.redraw = engine, rank, world, group, redraw
         # rank blocks instead of slabs: every rank's rows are the pedestrians of one rectangle of a gx x gy grid over the map
-        self.layout = block_layout(world) if (world > 1 and hasattr(engine, "set_partition")) else None
+        self.layout = block_layout(world, layout) if (world > 1 and hasattr(engine, "set_partition")) else None
         if self.layout:
             engine.set_partition(*self.layout)
         self.n, self.n_pad = engine.load(scenario, redraw=redraw)
@@ -236,8 +235,6 @@ class ShardedStepper:
             resort_every = int(os.environ.get("SFM_RESORT_EVERY", "64"))
         self.resort_every = resort_every
         self.since_resort = 0
-        if balance is None:
-            balance = os.environ.get("SFM_BALANCE", "1") != "0"
         self.balance = balance and world > 1 and hasattr(engine, "work")
         self._plans = {}
 

@@ -26,7 +26,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-REF = os.environ.get("SFM_REFERENCE", "/root/reference")
+REF = os.environ.get("UPSTREAM_REFERENCE", "/root/reference")
 
 if not os.path.isdir(REF):
     print(f"make_golden: reference checkout {REF} not present -- nothing to do")

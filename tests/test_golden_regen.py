@@ -12,7 +12,7 @@ import pytest
 
 import _golden_io as gio
 
-REF = os.environ.get("SFM_REFERENCE", "/root/reference")
+REF = os.environ.get("UPSTREAM_REFERENCE", "/root/reference")
 CASES = ["all_s0_n16", "all_s1_n64", "modes_n32", "c1_n64", "coincident_n8", "zspread_n64"]
 
 

@@ -262,11 +262,9 @@ def test_gap_acceptance_and_vehicle_rings_agree_with_the_oracles_restatement():
         assert np.max(np.abs(scenarios.ellipse_ring(scenarios._f32(c), yaw, ex, ey) - want)) <= 1e-4
 
 
-def test_block_layout_of_the_ranks(monkeypatch):
+def test_block_layout_of_the_ranks():
     from carla_social_force_model_amd.stepper import block_layout
-    monkeypatch.delenv("SFM_LAYOUT", raising=False)
     assert [block_layout(w) for w in (1, 2, 3, 4, 6, 8)] == [(1, 1), (1, 2), (3, 1), (2, 2), (3, 2), (2, 4)]
-    monkeypatch.setenv("SFM_LAYOUT", "8,1")
-    assert block_layout(8) == (8, 1)
+    assert block_layout(8, (8, 1)) == (8, 1)
     with pytest.raises(ValueError):
-        block_layout(4)
+        block_layout(4, (8, 1))

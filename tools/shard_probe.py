@@ -1,7 +1,7 @@
 """Per-rank compute time of the sharded path, replayed on one GPU: the whole crowd is resident on one handle and rank r of G
 is replayed by sfm_set_shard(rows of r).  No collective here -- this is the compute a rank does between two all-gathers.
 
-    python tools/shard_probe.py c5 [G ...]          default G = 1 2 4 8;  SFM_LAYOUT=gx,gy picks the rank blocks (default: stepper.block_layout)
+    python tools/shard_probe.py c5 [G ...]          default G = 1 2 4 8;  LAYOUT=gx,gy picks the rank blocks (default: stepper.block_layout)
 
 For every G (a fresh handle each): the equal split, then `PROBE_ITER` rounds of stepper.balanced_bounds on the engine's work
 measure, each followed by the re-pack that cuts the blocks at the new boundaries (what ShardedStepper does at each re-pack).
@@ -22,7 +22,7 @@ Gs = [int(a) for a in sys.argv[2:]] or [1, 2, 4, 8]
 sc, forces = scenarios.baseline_scenario(name)
 t1 = None
 for G in Gs:
-    layout = block_layout(G) if G > 1 else None
+    layout = block_layout(G, [int(v) for v in os.environ["LAYOUT"].split(",")] if os.environ.get("LAYOUT") else None) if G > 1 else None
     eng = HipShardEngine(default_sfm_config(forces), 0.05)
     if layout:
         eng.set_partition(*layout)
@@ -39,7 +39,7 @@ for G in Gs:
             e.tick()
             ms, k, l = e.timing()
             t.append(ms / k * 1e3)
-        return sum(t) / len(t), l / k, eng.work()
+        return sum(t) / len(t), l / k, eng.work(), e.pair_work()[1]
 
     b = equal_bounds(n, n_pad, G)
     for it in range(ITER + 1 if G > 1 else 1):
@@ -58,6 +58,12 @@ for G in Gs:
               f"{t1 / max(us) if t1 else float('nan'):5.2f}x  launches/tick {res[0][1]:.1f}  kernel {e.kernel_variant()}", flush=True)
         print("      per rank us: " + " ".join(f"{u:7.1f}" for u in us), flush=True)
         print("      rows       : " + " ".join(f"{b[r + 1] - b[r]:7d}" for r in range(G)), flush=True)
+        # Moussaid terms the rank's pair kernel evaluated (own-own pairs once, pairs with another rank's tile one-sided: the other
+        # rank evaluates them too) against an eighth of what the whole crowd on one GPU evaluates
+        terms = [x[3] for x in res]
+        if G == 1:
+            terms1 = terms[0]
+        print("      pair terms : " + " ".join(f"{v / 1e6:7.1f}" for v in terms) + f"  M   (whole crowd / G = {terms1 / G / 1e6:.1f} M)", flush=True)
         if G > 1 and it < ITER:
             b = balanced_bounds(b, [x[2] for x in res], n)
     eng.close()
