@@ -94,8 +94,9 @@ struct SfmHandle {
 
     // symmetric pedestrian-force path (single shard, planar, no radius)
     float2* slab = nullptr;
+    float* slabz = nullptr;                // 3-D crowds: the z components (same indexing)
     int n_t = 0;
-    size_t slab_cap = 0;
+    size_t slab_cap = 0, slabz_cap = 0;
     int dpp_dir = 0;
     int sym_mode = -1;                     // SFM_SYM: 0 off, 1 on when eligible, -1 auto
     // tile-granular cutoff of provably negligible pedestrian pairs
@@ -426,6 +427,7 @@ int sfm_destroy(SfmHandle* h) {
     if (h->dyn_local) hipFree(h->dyn_local);
     if (h->dyn_rot) hipFree(h->dyn_rot);
     if (h->slab) hipFree(h->slab);
+    if (h->slabz) hipFree(h->slabz);
     if (h->fslab) hipFree(h->fslab);
     if (h->fgeo) hipFree(h->fgeo);
     if (h->dyn_ctr_alt) hipFree(h->dyn_ctr_alt);
@@ -786,8 +788,9 @@ int sfm_upload_state(SfmHandle* h, int N, const float* x, const float* y, const 
     // slab of the symmetric path: n_t x (n_t*64) float2 (8.6 GB at N = 262 144), up to 16 GiB of the 288 GB
     h->n_t = (N + WAVE - 1) / WAVE;
     const size_t need = (size_t)h->n_t * (size_t)slab_stride(h->n_t);
-    if (!z3 && h->dpp_dir != 0 && h->sym_mode != 0 && need * sizeof(float2) <= ((size_t)16 << 30)) {
+    if (h->dpp_dir == 1 && h->sym_mode != 0 && need * sizeof(float2) <= ((size_t)16 << 30)) {
         if (need > h->slab_cap) { HIP_TRY(h, dev_realloc(h->slab, need)); h->slab_cap = need; }
+        if (z3 && need > h->slabz_cap) { HIP_TRY(h, dev_realloc(h->slabz, need)); h->slabz_cap = need; }
     }
     // cutoff bookkeeping: per-tile box / max speed, and the work list of the symmetric kernel
     h->r_max = 0.f;
@@ -1051,7 +1054,7 @@ static SymArgs make_sym_args(const SfmHandle* h, const TickArgs& a, int tps, int
     const bool lite = a.lite != 0;
     const bool list = a.tile_box && !lite;
     const bool sched = lite && h->cost && h->sched_mode != 0 && (size_t)h->n_t * (size_t)(h->n_t / 2 + 1) <= h->cost_cap;
-    return SymArgs{h->slab, h->n_t, slab_stride(h->n_t), h->dpp_dir, debug_steps,
+    return SymArgs{h->slab, h->z3 ? h->slabz : nullptr, h->n_t, slab_stride(h->n_t), h->dpp_dir, debug_steps,
                    (list || sched) ? h->work : nullptr, (list || sched) ? h->work_count : nullptr, lite ? a.tile_box : nullptr,
                    (lite || list) ? a.tile_vmax : nullptr,
                    a.cut_scale, a.cut_pad, stamps, h->strip_box, h->strip_vmax, tps, n_strips,
@@ -1203,8 +1206,8 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags, int phase = PHASE_
     const bool whole = h->i_begin == 0 && h->i_end == h->N;
     const bool tile_shard = n_local > 0 && (h->i_begin % WAVE) == 0 && ((h->i_end % WAVE) == 0 || h->i_end == h->N) && list_cut &&
                             h->n_t < 32768;
-    const bool sym = !h->z3 && (whole || tile_shard) && h->slab && need <= h->slab_cap &&
-                     h->dpp_dir != 0 && h->prm.enabled[SFM_FORCE_PEDESTRIAN] &&
+    const bool sym = (whole || tile_shard) && h->slab && need <= h->slab_cap && (!h->z3 || (h->slabz && need <= h->slabz_cap)) &&
+                     h->dpp_dir == 1 && h->prm.enabled[SFM_FORCE_PEDESTRIAN] &&
                      (h->sym_mode == 1 || (h->sym_mode < 0 && h->N >= 256));
     h->used_sym = sym;
     if (sym) snprintf(h->variant, sizeof(h->variant), "sfm_pair_sym_kernel+sfm_sym_epilogue_kernel");
@@ -1215,7 +1218,7 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags, int phase = PHASE_
     //      Every sfm_run / sfm_run_recorded takes it, whatever its length -- what a device-resident run computes must not depend on
     //      how the caller cuts it into calls (a lone sfm_run(1) pays a launch in front like the two-launch tick pays its epilogue) --
     //      and a single sfm_tick when it carries on from such a run.
-    if (sym && whole && (plain || fused_geo) && phase == PHASE_FULL && (device_run || carry) && h->fused_mode != 0 &&
+    if (sym && whole && !h->z3 && (plain || fused_geo) && phase == PHASE_FULL && (device_run || carry) && h->fused_mode != 0 &&
         (flags & SFM_TICK_INTEGRATE) && !(flags & SFM_TICK_RECORD_FORCES) && !h->fsm_on && h->debug_steps < 0 && !h->stamps && !h->geo_stamps &&
         h->n_t >= 4)
         return run_fused(h, ticks, flags, carry, fused_geo);
@@ -1231,7 +1234,7 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags, int phase = PHASE_
         TickArgs a;
         fill_args(h, a, flags);
         const int t_lo = h->i_begin / WAVE, t_hi = (h->i_end + WAVE - 1) / WAVE;
-        HIP_TRY(h, launch_tile_bounds(a.pk_cur, nullptr, h->N, const_cast<float4*>(a.tile_box), const_cast<float*>(a.tile_vmax), h->stream,
+        HIP_TRY(h, launch_tile_bounds(a.pk_cur, h->z3 ? a.zv_cur : nullptr, h->N, const_cast<float4*>(a.tile_box), const_cast<float*>(a.tile_vmax), h->stream,
                                       t_lo, t_hi));
         const bool ahead = h->geo_ahead && a.geo;
         h->geo_ahead = false;

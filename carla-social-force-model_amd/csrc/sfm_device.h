@@ -119,6 +119,7 @@ struct TickArgs {
 // Symmetric (antisymmetry-exploiting) pedestrian-force path, single shard only.
 struct SymArgs {
     float2* slab;        // [n_t][stride]: slab[u][i] = -A-less force on pedestrian i from all pedestrians of tile u
+    float* slabz;        // 3-D crowds: its z component, same indexing (null: planar)
     int n_t;             // number of 64-pedestrian tiles
     int stride;          // n_t * 64
     int dir;             // lane direction of the DPP wavefront rotate (+1: lane l receives lane l+1), calibrated at init

@@ -193,6 +193,53 @@ __device__ __forceinline__ bool moussaid_planar(const IxConst& c, float dx, floa
     return true;
 }
 
+// The same for a 3-D crowd (round 3; pedestrian_state.py:17-19 keeps 3-component positions and velocities and forces.py:75-117
+// takes 3-component norms): e, D and t are 3-vectors, the force is f_v t + f_theta n with n = (-t_y, t_x, 0), and the angle is the
+// one between the xy-projections of e and t (stateutils.angle_diff_2d uses components 0 and 1 only) -- neither projection is a unit
+// vector, so the half-angle ratio is S / (h + |C|) with h = sqrt(S^2 + C^2) (one more rsq).  d2 is the 3-D squared distance.
+// Two pedestrians above one another (e_xy = 0) or a vertical D give h = 0 -> rsq(0) = inf -> NaN, the signal for the exact body
+// (np.arctan2(0, 0) = 0 there), like a coincident pair in the planar body.
+template <bool RAD, bool CUT>
+__device__ __forceinline__ bool moussaid_spatial(const IxConst& c, float dx, float dy, float dz, float d2, float wx, float wy, float wz,
+                                                 float rsum, float& cx, float& cy, float& cz) {
+    const float rinv = rsq(d2);
+    const float d = d2 * rinv;
+    const float Dx = fmaf(dx, rinv, wx), Dy = fmaf(dy, rinv, wy), Dz = fmaf(dz, rinv, wz);
+    const float D2 = fmaf(Dx, Dx, fmaf(Dy, Dy, fmaf(Dz, Dz, TINY)));
+    const float rD = rsq(D2);
+    const float deff = RAD ? d - rsum : d;
+    const float aL = deff * (rD * c.c1);
+    if (CUT && !__any(!(aL <= -41.0f))) return false;
+    const float Dn = D2 * rD;                                          // |D|
+    const float tx = Dx * rD, ty = Dy * rD, tz = Dz * rD;
+    const float S = fmaf(tx, dy, -(ty * dx));                          // |t_xy| |d_xy| sin(angle(e_xy) - angle(t_xy))
+    const float C = fmaf(tx, dx, ty * dy);                             // ... cos
+    const float h2 = fmaf(S, S, C * C);
+    const float h = h2 * rsq(h2);
+    const float r = S * rcp(h + fabsf(C));                             // tan(angle / 2) folded into [-1, 1] (see atan2_unit)
+    const float z = r * r;
+    float p = -0.0095607885413262813f;
+    p = fmaf(p, z, 0.049113825228842972f);
+    p = fmaf(p, z, -0.11980885478692463f);
+    p = fmaf(p, z, 0.1988547939908939f);
+    p = fmaf(p, z, -0.28058826128196529f);
+    p = fmaf(p, z, 0.39942748114880167f);
+    p = fmaf(p, z, -0.66664186893326649f);
+    p = fmaf(p, z, 1.9999998228145017f);
+    const float a = p * r;
+    const float ang = (C < 0.0f) ? (copysignf(3.14159265358979324f, S) - a) : a;
+    const float theta = fmaf(-c.eg, Dn, ang);                          // forces.py:101
+    const float q = Dn * theta;
+    const float q2 = q * q;
+    const float e1 = ex2(fmaf(q2, c.k1, aL));
+    const float e2 = ex2(fmaf(q2, c.k2, aL));
+    const float g = copysignf(e2, theta);
+    cx = fmaf(e1, tx, -(g * ty));
+    cy = fmaf(e1, ty, g * tx);
+    cz = e1 * tz;
+    return true;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
@@ -1353,13 +1400,16 @@ struct PairShared {                             // LDS of one pair workgroup
     int cnt[WAVES_PER_BLOCK];
     float4 trav[2][2 * WAVE];                   // the travelling tile(s) {x, y, lambda vx, lambda vy}, each twice back to back (two: a diagonal item)
     float radt[2][2 * WAVE];                    // ... and their radii (use_ped_radius)
+    float2 travz[2][2 * WAVE];                  // 3-D crowds: {z, lambda vz} of the travelling tile(s)
+    float fiz[WAVES_PER_BLOCK][WAVE];           // ... and the z components of the two sums
+    float fjz[WAVES_PER_BLOCK][WAVE];
 };
 
 // The body of sfm_pair_sym_kernel for workgroup (bid_x, bid_y) of a grid grid_x wide, callable from another kernel's workgroups as
 // well (sfm_pair_geo_kernel).
-template <bool RAD, bool CUT>
-__device__ __forceinline__ void pair_block(const float4* __restrict__ pk, const float* __restrict__ radius, const IxConst& c, const SymArgs& sa,
-                                           PairShared& sh, int bid_x, int bid_y, int grid_x, int tid) {
+template <bool RAD, bool CUT, bool Z3>
+__device__ __forceinline__ void pair_block(const float4* __restrict__ pk, const float2* __restrict__ zv, const float* __restrict__ radius, const IxConst& c,
+                                           const SymArgs& sa, PairShared& sh, int bid_x, int bid_y, int grid_x, int tid) {
     const int lane = tid & (WAVE - 1);
     const int wave = uniform(tid >> 6);
     const int n_t = sa.n_t;
@@ -1404,6 +1454,7 @@ __device__ __forceinline__ void pair_block(const float4* __restrict__ pk, const 
     if (sa.debug_steps >= 0) nsteps = sa.debug_steps;
 
     float fxi = 0.f, fyi = 0.f, fxj = 0.f, fyj = 0.f;
+    float fzi = 0.f, fzj = 0.f;                   // 3-D crowds (Z3): the z components (forces.py:112-117 keeps 3-component forces)
     int i_end_loc = lane;
     int executed = 0;                             // systolic steps this wave evaluated (uniform)
     bool negligible = false;                      // lite cutoff: the whole tile pair is provably below 2^-40 A
@@ -1416,12 +1467,15 @@ __device__ __forceinline__ void pair_block(const float4* __restrict__ pk, const 
         const float4 t = make_float4(q.x, q.y, c.lam * q.z, c.lam * q.w);
         sh.trav[tsel][lane] = t; sh.trav[tsel][lane + WAVE] = t;
         if (RAD) { const float r_ = radius[ta * WAVE + lane]; sh.radt[tsel][lane] = r_; sh.radt[tsel][lane + WAVE] = r_; }
+        if (Z3) { const float2 qz = zv[ta * WAVE + lane]; const float2 tz = make_float2(qz.x, c.lam * qz.y); sh.travz[tsel][lane] = tz; sh.travz[tsel][lane + WAVE] = tz; }
     }
     __syncthreads();
     if (ta >= 0) {
         const float4 pj = pk[tb * WAVE + lane];
         float rj = 0.f;
         if (RAD) rj = radius[tb * WAVE + lane];
+        float zj = 0.f, ujz = 0.f;
+        if (Z3) { const float2 qz = zv[tb * WAVE + lane]; zj = qz.x; ujz = c.lam * qz.y; }
         float reach2 = __builtin_inff();             // CUT: squared distance beyond which a term is < 2^-40 A (uniform)
         if (CUT && shift != 0) {
             // lite cutoff: every term of this tile pair is provably < 2^-40 A -> nothing to do; the epilogue applies the same
@@ -1435,34 +1489,44 @@ __device__ __forceinline__ void pair_block(const float4* __restrict__ pk, const 
         const float ujx = c.lam * pj.z, ujy = c.lam * pj.w;
         const float4* trav = &sh.trav[tsel][lane + sig0];
         const float* radt = &sh.radt[tsel][lane + sig0];
+        const float2* travz = &sh.travz[tsel][lane + sig0];
         // sigma = 32 on a diagonal tile meets every unordered pair {l, l+32} in BOTH lanes: one-sided there
         const int one_sided_from = one_sided ? 0 : ((diag && (sig0 + nsteps - 1 == 32)) ? nsteps - 1 : nsteps);   // uniform
         float4 T = trav[0];
         float ri = RAD ? radt[0] : 0.f;
+        float2 Tz = make_float2(0.f, 0.f);
+        if (Z3) Tz = travz[0];
         // (steps are not interleaved: measured on MI355X, round 2 -- eight waves per SIMD already hide a step's dependent chain;
         //  unrolled by four only so that the slot offsets are immediates of the LDS reads)
         auto step = [&](int s_) __attribute__((always_inline)) {
             const float4 Tn = trav[s_ + 1];       // the next step's operand is in flight during this one (slot <= 127: inside the image)
             float rin = 0.f;
             if (RAD) rin = radt[s_ + 1];
+            float2 Tzn = make_float2(0.f, 0.f);
+            if (Z3) Tzn = travz[s_ + 1];
             __builtin_amdgcn_sched_barrier(0);
             const float dx = pj.x - T.x, dy = pj.y - T.y;
-            const float d2 = fmaf(dx, dx, dy * dy);
+            const float dz = Z3 ? zj - Tz.x : 0.f;
+            const float d2 = Z3 ? fmaf(dx, dx, fmaf(dy, dy, dz * dz)) : fmaf(dx, dx, dy * dy);
             bool done = false;
             if (!CUT || __any(!(d2 > reach2))) {
-                float cx, cy;
-                if (moussaid_planar<RAD, CUT>(c, dx, dy, d2, T.z - ujx, T.w - ujy, RAD ? ri + rj : 0.f, cx, cy)) {
+                float cx, cy, cz = 0.f;
+                const bool kept = Z3 ? moussaid_spatial<RAD, CUT>(c, dx, dy, dz, d2, T.z - ujx, T.w - ujy, Tz.y - ujz, RAD ? ri + rj : 0.f, cx, cy, cz)
+                                     : moussaid_planar<RAD, CUT>(c, dx, dy, d2, T.z - ujx, T.w - ujy, RAD ? ri + rj : 0.f, cx, cy);
+                if (kept) {
                     // the sums of the pedestrian this lane has just met were in lane + 1 a step ago: rotation and add in one
                     fxi = rot_in(fxi) + cx;
                     fyi = rot_in(fyi) + cy;
-                    if (s_ < one_sided_from) { fxj -= cx; fyj -= cy; }
+                    if (Z3) fzi = rot_in(fzi) + cz;
+                    if (s_ < one_sided_from) { fxj -= cx; fyj -= cy; if (Z3) fzj -= cz; }
                     ++executed;
                     done = true;
                 }
             }
-            if (CUT && !done) { fxi = rot_in(fxi); fyi = rot_in(fyi); }
+            if (CUT && !done) { fxi = rot_in(fxi); fyi = rot_in(fyi); if (Z3) fzi = rot_in(fzi); }
             T = Tn;
             ri = rin;
+            Tz = Tzn;
             __builtin_amdgcn_sched_barrier(0);
         };
         if (nsteps == 16) {                      // the normal case: fixed trip count
@@ -1477,6 +1541,7 @@ __device__ __forceinline__ void pair_block(const float4* __restrict__ pk, const 
     }
     sh.fi[wave][i_end_loc] = make_float2(fxi, fyi);
     sh.fj[wave][lane] = make_float2(fxj, fyj);
+    if (Z3) { sh.fiz[wave][i_end_loc] = fzi; sh.fjz[wave][lane] = fzj; }
     if (sa.cost && lane == 0) sh.cnt[wave] = executed;
     __syncthreads();
     if (sa.cost && tid == 0) sa.cost[shift * n_t + bx] = (sh.cnt[0] + sh.cnt[1]) + (sh.cnt[2] + sh.cnt[3]);
@@ -1492,6 +1557,7 @@ __device__ __forceinline__ void pair_block(const float4* __restrict__ pk, const 
                 const float2 a0 = sh.fi[2 * g][p], a1 = sh.fi[2 * g + 1][p], b0 = sh.fj[2 * g][p], b1 = sh.fj[2 * g + 1][p];
                 sa.slab[(size_t)t * sa.stride + t * WAVE + p] = make_float2(((a0.x + a1.x) + b0.x) + b1.x,
                                                                             ((a0.y + a1.y) + b0.y) + b1.y);
+                if (Z3) sa.slabz[(size_t)t * sa.stride + t * WAVE + p] = ((sh.fiz[2 * g][p] + sh.fiz[2 * g + 1][p]) + sh.fjz[2 * g][p]) + sh.fjz[2 * g + 1][p];
             }
         }
     } else if (tid < 2 * WAVE) {
@@ -1499,9 +1565,11 @@ __device__ __forceinline__ void pair_block(const float4* __restrict__ pk, const 
         if (tid < WAVE) {     // force on tile ta's pedestrians from tile tb
             const float2 a0 = sh.fi[0][p], a1 = sh.fi[1][p], a2 = sh.fi[2][p], a3 = sh.fi[3][p];
             sa.slab[(size_t)tb * sa.stride + ta * WAVE + p] = make_float2(((a0.x + a1.x) + a2.x) + a3.x, ((a0.y + a1.y) + a2.y) + a3.y);
+            if (Z3) sa.slabz[(size_t)tb * sa.stride + ta * WAVE + p] = ((sh.fiz[0][p] + sh.fiz[1][p]) + sh.fiz[2][p]) + sh.fiz[3][p];
         } else if (!one_sided) {   // force on tile tb's pedestrians from tile ta
             const float2 a0 = sh.fj[0][p], a1 = sh.fj[1][p], a2 = sh.fj[2][p], a3 = sh.fj[3][p];
             sa.slab[(size_t)ta * sa.stride + tb * WAVE + p] = make_float2(((a0.x + a1.x) + a2.x) + a3.x, ((a0.y + a1.y) + a2.y) + a3.y);
+            if (Z3) sa.slabz[(size_t)ta * sa.stride + tb * WAVE + p] = ((sh.fjz[0][p] + sh.fjz[1][p]) + sh.fjz[2][p]) + sh.fjz[3][p];
         }
     }
     if (sa.work) __syncthreads();                 // LDS is reused by the next item
@@ -1522,11 +1590,11 @@ __device__ __forceinline__ void pair_block(const float4* __restrict__ pk, const 
 // term is below 2^-40 A given the largest speeds of the two tiles (tiles_negligible's bound, per pair instead of per box):
 // a systolic step whose 64 pairs are ALL farther apart than that costs two subtractions, two fmas, a compare and the
 // rotation.  The test is on the pair's own distance, so it needs no agreement with anything else.
-template <bool RAD, bool CUT>
-__global__ __launch_bounds__(BLOCK) void sfm_pair_sym_kernel(const float4* __restrict__ pk, const float* __restrict__ radius,
+template <bool RAD, bool CUT, bool Z3>
+__global__ __launch_bounds__(BLOCK) void sfm_pair_sym_kernel(const float4* __restrict__ pk, const float2* __restrict__ zv, const float* __restrict__ radius,
                                                              const IxConst c, const SymArgs sa) {
     __shared__ PairShared sh;
-    pair_block<RAD, CUT>(pk, radius, c, sa, sh, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x, (int)threadIdx.x);
+    pair_block<RAD, CUT, Z3>(pk, zv, radius, c, sa, sh, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x, (int)threadIdx.x);
 }
 
 // Geometry workgroups in front of the pair kernel's workgroups in ONE launch (whole mid-sized crowd, list cutoff): the border /
@@ -1534,7 +1602,7 @@ __global__ __launch_bounds__(BLOCK) void sfm_pair_sym_kernel(const float4* __res
 // are VALU work -- side by side on the CUs they overlap, which two launches on two streams do not at this size.
 // The geometry part runs as 4-wave workgroups, geo_slices of them per tile (the same 16 waves per tile as sfm_geometry_kernel),
 // so that both kinds share the block size; they come first in the grid and are therefore dispatched first.
-template <bool RAD, bool CUT>
+template <bool RAD, bool CUT, bool Z3>
 __global__ __launch_bounds__(BLOCK) void sfm_pair_geo_kernel(const TickArgs a, const SymArgs sa, int geo_tiles, int geo_stride) {
     constexpr size_t LDS = sizeof(GeoShared<WAVES_PER_BLOCK>) > sizeof(PairShared) ? sizeof(GeoShared<WAVES_PER_BLOCK>) : sizeof(PairShared);
     __shared__ __attribute__((aligned(16))) char smem[LDS];
@@ -1550,8 +1618,8 @@ __global__ __launch_bounds__(BLOCK) void sfm_pair_geo_kernel(const TickArgs a, c
                                              geo_tiles, (int)threadIdx.x);
     } else {
         const int pb = bid - min(n_geo, g + 1);   // index among the pair workgroups: a run of the list, or (bx, shift) of the 2-D grid
-        if (sa.work) pair_block<RAD, CUT>(a.pk_cur, a.radius, a.ped, sa, *reinterpret_cast<PairShared*>(smem), pb, 0, (int)gridDim.x - n_geo, (int)threadIdx.x);
-        else pair_block<RAD, CUT>(a.pk_cur, a.radius, a.ped, sa, *reinterpret_cast<PairShared*>(smem), pb % sa.n_t, pb / sa.n_t, sa.n_t, (int)threadIdx.x);
+        if (sa.work) pair_block<RAD, CUT, Z3>(a.pk_cur, a.zv_cur, a.radius, a.ped, sa, *reinterpret_cast<PairShared*>(smem), pb, 0, (int)gridDim.x - n_geo, (int)threadIdx.x);
+        else pair_block<RAD, CUT, Z3>(a.pk_cur, a.zv_cur, a.radius, a.ped, sa, *reinterpret_cast<PairShared*>(smem), pb % sa.n_t, pb / sa.n_t, sa.n_t, (int)threadIdx.x);
     }
 }
 
@@ -1625,10 +1693,12 @@ constexpr int EPI_WAVES = 16;
 #define EPI_INFLIGHT 8                     // slab-row loads a wave keeps in flight under a cutoff (a multiple of 4; the sum's association follows it)
 #endif
 
-template <bool RAD, int EW>
+template <bool RAD, int EW, bool Z3>
 __global__ __launch_bounds__(EW * WAVE) void sfm_sym_epilogue_kernel(const TickArgs a, const SymArgs sa) {
     __shared__ float2 s_sum[EW][WAVE];
     __shared__ float2 s_exact[WAVE];
+    __shared__ float s_sumz[Z3 ? EW : 1][WAVE];     // 3-D crowds: the z components
+    __shared__ float s_exactz[WAVE];
     __shared__ int s_bad[EW];
     __shared__ uint16_t s_own[EW][4096 / EW];   // two-level cutoff: the strips a wave sums (n_strips <= n_t <= 4096 under a cutoff)
     __shared__ uint16_t s_kept[EW][4 * WAVE];   // ... and the kept tiles of four of them
@@ -1658,11 +1728,14 @@ __global__ __launch_bounds__(EW * WAVE) void sfm_sym_epilogue_kernel(const TickA
 
     // own state first: independent of the slab, so its latency overlaps the column sum
     float4 st = make_float4(0.f, 0.f, 0.f, 0.f), o = st;
+    float2 stz = make_float2(0.f, 0.f);
     uint32_t nd0 = 0;
-    if (wave == 0 && i < i_end) { st = a.pk_cur[i]; o = a.own[i]; if (a.flags & 2u) nd0 = a.draws[i]; }
+    if (wave == 0 && i < i_end) { st = a.pk_cur[i]; o = a.own[i]; if (a.flags & 2u) nd0 = a.draws[i]; if (Z3) stz = a.zv_cur[i]; }
 
     // 1. slab column sums
     float2 acc = make_float2(0.f, 0.f);
+    float accz = 0.f;
+    const float* colz = Z3 ? sa.slabz + i : nullptr;
     if (a.en_ped && a.tile_box && sa.n_strips > 0) {
         // cutoff on, large crowd (sfm_pair_list2_kernel's two levels: a negligible strip holds only negligible tiles).  Three
         // passes, each with all of its loads in flight together instead of a round trip per strip (this kernel is a latency
@@ -1712,13 +1785,17 @@ __global__ __launch_bounds__(EW * WAVE) void sfm_sym_epilogue_kernel(const TickA
             }
             for (int r = 0; r < n_kept; r += EPI_INFLIGHT) {
                 float2 v[EPI_INFLIGHT];
+                float vz[EPI_INFLIGHT];
 #pragma unroll
-                for (int q = 0; q < EPI_INFLIGHT; ++q)
+                for (int q = 0; q < EPI_INFLIGHT; ++q) {
                     v[q] = (r + q < n_kept) ? col[(size_t)kept[r + q] * sa.stride] : make_float2(0.f, 0.f);
+                    vz[q] = (Z3 && r + q < n_kept) ? colz[(size_t)kept[r + q] * sa.stride] : 0.f;
+                }
 #pragma unroll
                 for (int q = 0; q < EPI_INFLIGHT; q += 4) {
                     acc.x += (v[q].x + v[q + 1].x) + (v[q + 2].x + v[q + 3].x);
                     acc.y += (v[q].y + v[q + 1].y) + (v[q + 2].y + v[q + 3].y);
+                    if (Z3) accz += (vz[q] + vz[q + 1]) + (vz[q + 2] + vz[q + 3]);
                 }
             }
         }
@@ -1753,13 +1830,17 @@ __global__ __launch_bounds__(EW * WAVE) void sfm_sym_epilogue_kernel(const TickA
             }
             for (int r = 0; r < n_kept; r += EPI_INFLIGHT) {
                 float2 v[EPI_INFLIGHT];
+                float vz[EPI_INFLIGHT];
 #pragma unroll
-                for (int q = 0; q < EPI_INFLIGHT; ++q)
+                for (int q = 0; q < EPI_INFLIGHT; ++q) {
                     v[q] = (r + q < n_kept) ? col[(size_t)kept[r + q] * sa.stride] : make_float2(0.f, 0.f);
+                    vz[q] = (Z3 && r + q < n_kept) ? colz[(size_t)kept[r + q] * sa.stride] : 0.f;
+                }
 #pragma unroll
                 for (int q = 0; q < EPI_INFLIGHT; q += 4) {
                     acc.x += (v[q].x + v[q + 1].x) + (v[q + 2].x + v[q + 3].x);
                     acc.y += (v[q].y + v[q + 1].y) + (v[q + 2].y + v[q + 3].y);
+                    if (Z3) accz += (vz[q] + vz[q + 1]) + (vz[q + 2] + vz[q + 3]);
                 }
             }
         }
@@ -1771,18 +1852,21 @@ __global__ __launch_bounds__(EW * WAVE) void sfm_sym_epilogue_kernel(const TickA
             const float2 v2 = col[(size_t)(u + 2 * EW) * sa.stride], v3 = col[(size_t)(u + 3 * EW) * sa.stride];
             acc.x += (v0.x + v1.x) + (v2.x + v3.x);
             acc.y += (v0.y + v1.y) + (v2.y + v3.y);
+            if (Z3) accz += (colz[(size_t)u * sa.stride] + colz[(size_t)(u + EW) * sa.stride]) + (colz[(size_t)(u + 2 * EW) * sa.stride] + colz[(size_t)(u + 3 * EW) * sa.stride]);
         }
         for (; u < sa.n_t; u += EW) {
             const float2 v = col[(size_t)u * sa.stride];
             acc.x += v.x;
             acc.y += v.y;
+            if (Z3) accz += colz[(size_t)u * sa.stride];
         }
     }
     s_sum[wave][lane] = acc;
+    if (Z3) s_sumz[Z3 ? wave : 0][lane] = accz;
     // A coincident pair leaves a NaN (moussaid_planar) in the sums of both pedestrians: any non-finite partial sum sends the
     // whole tile through the exact body below.
     {
-        const bool bad = !(fabsf(acc.x) < __builtin_inff()) || !(fabsf(acc.y) < __builtin_inff());
+        const bool bad = !(fabsf(acc.x) < __builtin_inff()) || !(fabsf(acc.y) < __builtin_inff()) || (Z3 && !(fabsf(accz) < __builtin_inff()));
         if (lane == 0) s_bad[wave] = 0;
         if (bad) s_bad[wave] = 1;                                  // same wave, LDS operations in order
     }
@@ -1802,20 +1886,26 @@ __global__ __launch_bounds__(EW * WAVE) void sfm_sym_epilogue_kernel(const TickA
             if (ip >= i_end) break;
             const float4 si = a.pk_cur[ip];
             const float xi = uniform(si.x), yi = uniform(si.y), vxi = uniform(si.z), vyi = uniform(si.w);
-            float gx = 0.f, gy = 0.f;
+            float zi = 0.f, vzi = 0.f;
+            if (Z3) { const float2 sz = a.zv_cur[ip]; zi = uniform(sz.x); vzi = uniform(sz.y); }
+            float gx = 0.f, gy = 0.f, gz = 0.f;
             for (int j0 = 0; j0 < N; j0 += WAVE) {
                 const int j = j0 + lane;
                 const float4 pj = a.pk_cur[min(j, N - 1)];
+                float2 pz = make_float2(0.f, 0.f);
+                if (Z3) pz = a.zv_cur[min(j, N - 1)];
                 float cx = 0.f, cy = 0.f, cz = 0.f, rinv;
-                moussaid<false, RAD, true>(a.ped, pj.x - xi, pj.y - yi, 0.f, vxi - pj.z, vyi - pj.w, 0.f,
-                                           RAD ? a.radius[ip] + a.radius[min(j, N - 1)] : 0.f, cx, cy, cz, rinv);
+                moussaid<Z3, RAD, true>(a.ped, pj.x - xi, pj.y - yi, pz.x - zi, vxi - pj.z, vyi - pj.w, vzi - pz.y,
+                                        RAD ? a.radius[ip] + a.radius[min(j, N - 1)] : 0.f, cx, cy, cz, rinv);
                 const bool valid = (j < N) & (j != ip);
                 gx += valid ? cx : 0.f;
                 gy += valid ? cy : 0.f;
+                if (Z3) gz += valid ? cz : 0.f;
             }
             gx = wave_sum(gx);
             gy = wave_sum(gy);
-            if (lane == 0) s_exact[p] = make_float2(gx, gy);
+            if (Z3) gz = wave_sum(gz);
+            if (lane == 0) { s_exact[p] = make_float2(gx, gy); s_exactz[p] = gz; }
         }
     }
     if (exact) __syncthreads();
@@ -1827,7 +1917,15 @@ __global__ __launch_bounds__(EW * WAVE) void sfm_sym_epilogue_kernel(const TickA
 #pragma unroll
     for (int w = 1; w < EW; ++w) { const float2 b = s_sum[w][lane]; g.x += b.x; g.y += b.y; }
     if (exact) g = s_exact[lane];
+    float gz = 0.f;
+    if (Z3) {
+        gz = s_sumz[0][lane];
+#pragma unroll
+        for (int w = 1; w < (Z3 ? EW : 1); ++w) gz += s_sumz[w][lane];
+        if (exact) gz = s_exactz[lane];
+    }
     const float fpx = a.en_ped ? a.ped.negA * g.x : 0.f, fpy = a.en_ped ? a.ped.negA * g.y : 0.f;
+    const float fpz = (Z3 && a.en_ped) ? a.ped.negA * gz : 0.f;
     float fbx = 0.f, fby = 0.f, fsx = 0.f, fsy = 0.f, fdx = 0.f, fdy = 0.f;
     if (a.geo) {
         const size_t np_ = (size_t)a.N_pad;
@@ -1838,22 +1936,25 @@ __global__ __launch_bounds__(EW * WAVE) void sfm_sym_epilogue_kernel(const TickA
         }
     }
     const float x = st.x, y = st.y, vx = st.z, vy = st.w, ts = o.z;
+    const float z = stz.x, vz = stz.y;
     float wx = o.x, wy = o.y;
-    float fax = 0.f, fay = 0.f;
+    float fax = 0.f, fay = 0.f, faz = 0.f;
     if (a.en_acc) {
         const float tx_ = wx - x, ty_ = wy - y;
         const float nrm = sqrtf(fmaf(tx_, tx_, ty_ * ty_));
         const float inv = (nrm == 0.0f) ? 1.0f : 1.0f / nrm;
         fax = (ts * (tx_ * inv) - vx) * a.inv_tau;
         fay = (ts * (ty_ * inv) - vy) * a.inv_tau;
+        if (Z3) faz = (0.0f - vz) * a.inv_tau;                     // the desired direction has no z (stateutils.py:12-13)
     }
     const float Fx = (((fax + fpx) + fbx) + fsx) + fdx;
     const float Fy = (((fay + fpy) + fby) + fsy) + fdy;
-    float nvx = fmaf(a.dt, Fx, vx), nvy = fmaf(a.dt, Fy, vy);
-    float sp = sqrtf(fmaf(nvx, nvx, nvy * nvy));
+    const float Fz = faz + fpz;
+    float nvx = fmaf(a.dt, Fx, vx), nvy = fmaf(a.dt, Fy, vy), nvz = Z3 ? fmaf(a.dt, Fz, vz) : 0.f;
+    float sp = Z3 ? sqrtf(fmaf(nvx, nvx, fmaf(nvy, nvy, nvz * nvz))) : sqrtf(fmaf(nvx, nvx, nvy * nvy));   // cap on the 3-D speed (stateutils.py:18-23)
     sp = (sp == 0.0f) ? 1.0f : sp;
     const float fac = fminf(1.0f, (ts * a.max_speed_factor) / sp);
-    nvx *= fac; nvy *= fac;
+    nvx *= fac; nvy *= fac; nvz *= fac;
     const uint32_t pid = live ? (a.ids ? a.ids[i] : (uint32_t)i) : 0u;
     bool despawn = false;
     const bool gone = live && a.fsm.mode && a.fsm.mode[pid] == MODE_DESPAWNED;
@@ -1872,15 +1973,16 @@ __global__ __launch_bounds__(EW * WAVE) void sfm_sym_epilogue_kernel(const TickA
             a.draws[i] = nd;
         }
     }
-    float nx = x, ny = y;
-    if (a.flags & 1u) { nx = fmaf(a.dt, nvx, x); ny = fmaf(a.dt, nvy, y); }
-    if (despawn || gone) { const float2 pp = park_position(pid); nx = pp.x; ny = pp.y; nvx = 0.f; nvy = 0.f; }
+    float nx = x, ny = y, nz = z;
+    if (a.flags & 1u) { nx = fmaf(a.dt, nvx, x); ny = fmaf(a.dt, nvy, y); if (Z3) nz = fmaf(a.dt, nvz, z); }
+    if (despawn || gone) { const float2 pp = park_position(pid); nx = pp.x; ny = pp.y; nvx = 0.f; nvy = 0.f; nvz = 0.f; }
     if (live) a.pk_next[i] = make_float4(nx, ny, nvx, nvy);
+    if (Z3 && live) a.zv_next[i] = make_float2(nz, nvz);
     if (a.tile_box_out) {                             // lite cutoff: box and largest speed of the tile in the NEXT state
         const float inf = __builtin_inff();
         const bool in_box = live && fabsf(nx) < 1.0e14f;
         float x0 = in_box ? nx : inf, y0 = in_box ? ny : inf, x1 = in_box ? nx : -inf, y1 = in_box ? ny : -inf;
-        float v = in_box ? sqrtf(fmaf(nvx, nvx, nvy * nvy)) * 1.000001f : 0.0f;
+        float v = in_box ? sqrtf(fmaf(nvx, nvx, fmaf(nvy, nvy, nvz * nvz))) * 1.000001f : 0.0f;
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) {
             x0 = fminf(x0, __shfl_xor(x0, m)); y0 = fminf(y0, __shfl_xor(y0, m));
@@ -1892,12 +1994,12 @@ __global__ __launch_bounds__(EW * WAVE) void sfm_sym_epilogue_kernel(const TickA
     if (a.rec && live) {
         float* rc = a.rec;
         const size_t n = (size_t)N;
-        rc[(0 * 3 + 0) * n + i] = fax; rc[(0 * 3 + 1) * n + i] = fay; rc[(0 * 3 + 2) * n + i] = 0.f;
-        rc[(1 * 3 + 0) * n + i] = fpx; rc[(1 * 3 + 1) * n + i] = fpy; rc[(1 * 3 + 2) * n + i] = 0.f;
+        rc[(0 * 3 + 0) * n + i] = fax; rc[(0 * 3 + 1) * n + i] = fay; rc[(0 * 3 + 2) * n + i] = faz;
+        rc[(1 * 3 + 0) * n + i] = fpx; rc[(1 * 3 + 1) * n + i] = fpy; rc[(1 * 3 + 2) * n + i] = fpz;
         rc[(2 * 3 + 0) * n + i] = fbx; rc[(2 * 3 + 1) * n + i] = fby; rc[(2 * 3 + 2) * n + i] = 0.f;
         rc[(3 * 3 + 0) * n + i] = fsx; rc[(3 * 3 + 1) * n + i] = fsy; rc[(3 * 3 + 2) * n + i] = 0.f;
         rc[(4 * 3 + 0) * n + i] = fdx; rc[(4 * 3 + 1) * n + i] = fdy; rc[(4 * 3 + 2) * n + i] = 0.f;
-        rc[(5 * 3 + 0) * n + i] = Fx;  rc[(5 * 3 + 1) * n + i] = Fy;  rc[(5 * 3 + 2) * n + i] = 0.f;
+        rc[(5 * 3 + 0) * n + i] = Fx;  rc[(5 * 3 + 1) * n + i] = Fy;  rc[(5 * 3 + 2) * n + i] = Fz;
     }
 }
 
@@ -2423,7 +2525,14 @@ int sym_item_count(int n_t);
 template <bool RAD, bool CUT>
 static void launch_sym_pair_t(dim3 grid, const TickArgs& a, const SymArgs& sa, hipStream_t st) {
     static const int pad_lds = exp_env("SFM_PAIR_LDS") ? atoi(exp_env("SFM_PAIR_LDS")) : 0;   // experiment: limits the resident workgroups per CU
-    hipLaunchKernelGGL((sfm_pair_sym_kernel<RAD, CUT>), grid, dim3(BLOCK), (size_t)pad_lds, st, a.pk_cur, a.radius, a.ped, sa);
+    if (sa.slabz) hipLaunchKernelGGL((sfm_pair_sym_kernel<RAD, CUT, true>), grid, dim3(BLOCK), (size_t)pad_lds, st, a.pk_cur, a.zv_cur, a.radius, a.ped, sa);
+    else hipLaunchKernelGGL((sfm_pair_sym_kernel<RAD, CUT, false>), grid, dim3(BLOCK), (size_t)pad_lds, st, a.pk_cur, a.zv_cur, a.radius, a.ped, sa);
+}
+
+template <bool RAD, bool CUT>
+static void launch_sym_pair_geo_t(dim3 grid, const TickArgs& a, const SymArgs& sa, int tiles, int stride, hipStream_t st) {
+    if (sa.slabz) hipLaunchKernelGGL((sfm_pair_geo_kernel<RAD, CUT, true>), grid, dim3(BLOCK), 0, st, a, sa, tiles, stride);
+    else hipLaunchKernelGGL((sfm_pair_geo_kernel<RAD, CUT, false>), grid, dim3(BLOCK), 0, st, a, sa, tiles, stride);
 }
 
 hipError_t launch_sym_pair(bool rad, const TickArgs& a, const SymArgs& sa, hipStream_t st) {
@@ -2455,10 +2564,8 @@ hipError_t launch_sym_pair_geo(bool rad, const TickArgs& a, const SymArgs& sa, h
     if (stride_ov > 0) stride = std::min(stride_ov, std::max(1, (n_geo + n_pair) / n_geo));
     if (stride > 1 && !(stride & 1)) --stride;      // odd: workgroup w runs on CU w mod 256, an even stride would put every geometry workgroup on a few CUs
     const bool cut = sa.vmax != nullptr;           // as launch_sym_pair: list (or lite) cutoff -> the per-step tests are on
-    if (rad) { if (cut) hipLaunchKernelGGL((sfm_pair_geo_kernel<true, true>), grid, dim3(BLOCK), 0, st, a, sa, tiles, stride);
-               else hipLaunchKernelGGL((sfm_pair_geo_kernel<true, false>), grid, dim3(BLOCK), 0, st, a, sa, tiles, stride); }
-    else { if (cut) hipLaunchKernelGGL((sfm_pair_geo_kernel<false, true>), grid, dim3(BLOCK), 0, st, a, sa, tiles, stride);
-           else hipLaunchKernelGGL((sfm_pair_geo_kernel<false, false>), grid, dim3(BLOCK), 0, st, a, sa, tiles, stride); }
+    if (rad) { if (cut) launch_sym_pair_geo_t<true, true>(grid, a, sa, tiles, stride, st); else launch_sym_pair_geo_t<true, false>(grid, a, sa, tiles, stride, st); }
+    else { if (cut) launch_sym_pair_geo_t<false, true>(grid, a, sa, tiles, stride, st); else launch_sym_pair_geo_t<false, false>(grid, a, sa, tiles, stride, st); }
     return hipGetLastError();
 }
 
@@ -2493,7 +2600,9 @@ static void launch_sym_epilogue_t(const TickArgs& a, const SymArgs& sa, hipStrea
     const int extra = a.adv.M > 0 ? (a.adv.M + EW - 1) / EW : 0;
     const int sched = (sa.cost && EW == EPI_WAVES) ? 1 : 0;   // scheduled lite cutoff: one more workgroup deals the next tick's order
     sb.sched_block = sched ? sa.t_hi - sa.t_lo + extra : -1;
-    hipLaunchKernelGGL((sfm_sym_epilogue_kernel<RAD, EW>), dim3(sa.t_hi - sa.t_lo + extra + sched), dim3(EW * WAVE), 0, st, b, sb);
+    const dim3 grid(sa.t_hi - sa.t_lo + extra + sched);
+    if (sa.slabz) hipLaunchKernelGGL((sfm_sym_epilogue_kernel<RAD, EW, true>), grid, dim3(EW * WAVE), 0, st, b, sb);
+    else hipLaunchKernelGGL((sfm_sym_epilogue_kernel<RAD, EW, false>), grid, dim3(EW * WAVE), 0, st, b, sb);
 }
 
 // 16 waves per tile for small and mid-sized crowds (one dependent round of slab-row loads); from 1024 tiles on there are
