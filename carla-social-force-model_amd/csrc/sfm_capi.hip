@@ -20,7 +20,7 @@ hipError_t launch_arrived(const float4* pk, const float4* own, int N, float thr2
 hipError_t launch_sym_list(const TickArgs& a, const SymArgs& sa, hipStream_t st, int partners = 0, bool count_is_zero = false);
 hipError_t launch_sym_pair(bool rad, const TickArgs& a, const SymArgs& sa, hipStream_t st);
 hipError_t launch_sym_epilogue(bool rad, const TickArgs& a, const SymArgs& sa, hipStream_t st);
-hipError_t launch_fused_tick(bool rad, const TickArgs& a, const FusedArgs& f, hipStream_t st, int waves, int sys);
+hipError_t launch_fused_tick(bool rad, const TickArgs& a, const FusedArgs& f, hipStream_t st, int waves);
 int fused_pair_workgroups(int n_g);
 hipError_t launch_sym_pair_geo(bool rad, const TickArgs& a, const SymArgs& sa, hipStream_t st);
 hipError_t launch_schedule(const int* cost, int n_t, uint32_t* work, int* count, hipStream_t st);
@@ -149,6 +149,8 @@ struct SfmHandle {
     // fused tick (sfm_fused_tick_kernel): one launch per tick inside sfm_run for a whole planar crowd without border / obstacle forces
     float2* fslab = nullptr;               // [2][n_g][N_pad] partial forces, ping-pong across launches
     size_t fslab_cap = 0;
+    float* fslabz = nullptr;               // 3-D crowds: their z components
+    size_t fslabz_cap = 0;
     float4* own_alt = nullptr;             // the waypoints ping-pong with the state
     int own_alt_cap = 0;
     int pair_geo_mode = -1;                // SFM_PAIR_GEO=0: the geometry kernel always gets a launch of its own (A/B, tests)
@@ -162,7 +164,6 @@ struct SfmHandle {
     size_t dyn_ctr_alt_cap = 0, dyn_pts_alt_cap = 0;
     int fused_geo_slices = 0;              // SFM_FUSED_GEO_SLICES: A/B
     int fused_geo_mode = -1;               // SFM_FUSED_GEO=0: crowds with border / obstacle forces keep the two-launch tick (A/B, tests)
-    int fused_sys = 1;                         // SFM_FUSED_SYS=0: the travelling tile in registers (DPP rotation) instead of LDS (A/B)
     bool used_fused = false;
     // A fused run ends with the partial forces of its final state already in fslab: the next sfm_run / sfm_tick carries on from
     // there (one launch per tick, no start-up launch) provided NOTHING else was called on the handle in between -- api_seq counts
@@ -353,8 +354,6 @@ int sfm_create(const SfmParams* params, int device_id, SfmHandle** out) {
     if (ov && atoi(ov) == 8) h->fused_waves = 8;
     ov = exp_env("SFM_FUSED_BLOCKED");
     if (ov) h->fused_blocked = atoi(ov);
-    ov = exp_env("SFM_FUSED_SYS");
-    if (ov) h->fused_sys = atoi(ov);
     ov = exp_env("SFM_FUSED_GEO");
     if (ov) h->fused_geo_mode = atoi(ov);
     ov = exp_env("SFM_FUSED_GEO_SLICES");
@@ -430,6 +429,7 @@ int sfm_destroy(SfmHandle* h) {
     if (h->slabz) hipFree(h->slabz);
     if (h->fslab) hipFree(h->fslab);
     if (h->fgeo) hipFree(h->fgeo);
+    if (h->fslabz) hipFree(h->fslabz);
     if (h->dyn_ctr_alt) hipFree(h->dyn_ctr_alt);
     if (h->dyn_pts_alt) hipFree(h->dyn_pts_alt);
     if (h->own_alt) hipFree(h->own_alt);
@@ -1093,11 +1093,12 @@ static int fused_launch(SfmHandle* h, uint32_t flags, int mode, int* sl) {
         a.adv.ctr_out = mode ? h->dynamics.ctr : h->dyn_ctr_alt;
         a.adv.pts_out = mode ? h->dynamics.pts : h->dyn_pts_alt;
     }
-    const FusedArgs f{h->fslab + (size_t)(*sl ^ 1) * rows, h->fslab + (size_t)*sl * rows, h->own, h->own_alt, n_g, h->n_t, h->dpp_dir,
-                      (h->fused_blocked != 0 && n_g % 8 == 0) ? 1 : 0,
+    const FusedArgs f{h->fslab + (size_t)(*sl ^ 1) * rows, h->fslab + (size_t)*sl * rows,
+                      h->z3 ? h->fslabz + (size_t)(*sl ^ 1) * rows : nullptr, h->z3 ? h->fslabz + (size_t)*sl * rows : nullptr,
+                      h->own, h->own_alt, n_g, h->n_t, (h->fused_blocked != 0 && n_g % 8 == 0) ? 1 : 0,
                       geo ? h->fgeo + (size_t)(*sl ^ 1) * grow : nullptr, geo ? h->fgeo + (size_t)*sl * grow : nullptr, slices,
                       geo ? h->n_t * slices : 0, n_pair, mode};
-    HIP_TRY(h, launch_fused_tick(h->rad, a, f, h->stream, nw, (h->fused_sys != 0 && h->dpp_dir == 1) ? 1 : 0));
+    HIP_TRY(h, launch_fused_tick(h->rad, a, f, h->stream, nw));
     if (mode != 0) {
         h->cur ^= 1;
         std::swap(h->own, h->own_alt);
@@ -1113,6 +1114,7 @@ static int fused_launch(SfmHandle* h, uint32_t flags, int mode, int* sl) {
 static int fused_reserve(SfmHandle* h) {
     const size_t need = (size_t)2 * (size_t)((h->n_t + 1) / 2) * (size_t)h->N_pad;
     if (need > h->fslab_cap) { HIP_TRY(h, dev_realloc(h->fslab, need)); h->fslab_cap = need; }
+    if (h->z3 && need > h->fslabz_cap) { HIP_TRY(h, dev_realloc(h->fslabz, need)); h->fslabz_cap = need; }
     if (h->own_alt_cap < h->cap) { HIP_TRY(h, dev_realloc(h->own_alt, (size_t)h->cap)); h->own_alt_cap = h->cap; }   // same size as own: they swap
     const size_t gneed = (size_t)2 * 4 * (size_t)h->N_pad;
     if (gneed > h->fgeo_cap) { HIP_TRY(h, dev_realloc(h->fgeo, gneed)); h->fgeo_cap = gneed; }
@@ -1218,7 +1220,7 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags, int phase = PHASE_
     //      Every sfm_run / sfm_run_recorded takes it, whatever its length -- what a device-resident run computes must not depend on
     //      how the caller cuts it into calls (a lone sfm_run(1) pays a launch in front like the two-launch tick pays its epilogue) --
     //      and a single sfm_tick when it carries on from such a run.
-    if (sym && whole && !h->z3 && (plain || fused_geo) && phase == PHASE_FULL && (device_run || carry) && h->fused_mode != 0 &&
+    if (sym && whole && (plain || fused_geo) && phase == PHASE_FULL && (device_run || carry) && h->fused_mode != 0 &&
         (flags & SFM_TICK_INTEGRATE) && !(flags & SFM_TICK_RECORD_FORCES) && !h->fsm_on && h->debug_steps < 0 && !h->stamps && !h->geo_stamps &&
         h->n_t >= 4)
         return run_fused(h, ticks, flags, carry, fused_geo);

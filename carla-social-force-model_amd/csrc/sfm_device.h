@@ -156,11 +156,12 @@ struct SymArgs {
 struct FusedArgs {
     const float2* slab_prev;  // [n_g][N_pad]: slab[r][i] = -A-less force on pedestrian i from the pedestrians of group r, previous state
     float2* slab_next;        // the same for the state this launch integrates to
+    const float* slabz_prev;  // 3-D crowds: the z components, same indexing (null: planar)
+    float* slabz_next;
     const float4* own_cur;    // {wx, wy, target_speed, radius} going with pk_cur
     float4* own_next;
     int n_g;                  // groups of two tiles
     int n_t;
-    int dir;                  // as SymArgs::dir
     int blocked;              // 1: XCD-aware order of the work items (n_g a multiple of 8)
     const float2* geo_prev;   // [geo_slices][N_pad]: border + obstacle forces on the stored state, one partial sum per slice of the polylines
     float2* geo_next;         // the same for the state this launch integrates to

@@ -2020,21 +2020,22 @@ __global__ __launch_bounds__(EW * WAVE) void sfm_sym_epilogue_kernel(const TickA
 // the exact body (by every workgroup that holds them).
 constexpr int GROUP = 2 * WAVE;                  // pedestrians per group of two tiles
 
-// SYS selects how the travelling tile reaches the lanes in the pair phase:
-//   0  in registers, rotated through the wavefront with DPP moves (4 operand moves + 2 accumulator moves per step: sfm_pair_sym_kernel's step)
-//   1  from LDS (round 3): the tile sits in LDS twice back to back, {x, y, lambda vx, lambda vy} per pedestrian, and step s of a lane is
-//      ONE ds_read_b128 at an immediate offset 16 s from the lane's base address -- no operand moves between lanes on the VALU.  Only
-//      the two sums of the travelling side still rotate, and their rotation is folded into the add (v_add_f32_dpp wave_rol:1: the sum
-//      arrives from the neighbouring lane and takes this step's term in one instruction).  60 -> 54 issued VALU instructions per step,
-//      the six v_mov_b32_dpp (half rate) among those gone.  Needs wave_rol:1 to hand lane l the value of lane l+1 (probed at init).
-//      (Measured and dropped: the sums in LDS as well, by ds_add_f32 -- LDS float atomics run at ~2 cycles per LANE: 88.8 against 17.5 us.)
+// The travelling tile reaches the lanes from LDS (round 3; round 2 rotated it through the wavefront in registers, six v_mov_b32_dpp
+// per step): the tile sits in LDS twice back to back, {x, y, lambda vx, lambda vy} per pedestrian, and step s of a lane is ONE
+// ds_read_b128 at an immediate offset 16 s from the lane's base address -- no operand moves between lanes on the VALU.  Only the
+// sums of the travelling side still rotate, and their rotation is folded into the add (v_add_f32_dpp wave_rol:1: the sum arrives
+// from the neighbouring lane and takes this step's term in one instruction).  60 -> 54 issued VALU instructions per step: c2 17.55
+// -> 16.54 us.  Needs wave_rol:1 to hand lane l the value of lane l+1 (probed at init; otherwise the symmetric path is off).
+// (Measured and dropped: the sums in LDS as well, by ds_add_f32 -- LDS float atomics run at ~2 cycles per LANE: 88.8 against 17.5 us.)
+// Z3: a 3-D crowd -- {z, lambda vz} travel beside (one more ds_read_b64), the body is moussaid_spatial, the sums have a z component
+// that goes through slabz rows, and the integration is the 3-D one of sfm_sym_epilogue_kernel.
 // GEO (round 3): the crowd also feels border / obstacle forces.  Their workgroups are a second ROLE of the same launch -- blocks
 // [0, n_geo_wg): one workgroup per (tile, slice of the polylines); it integrates its tile's group exactly like a pair workgroup
 // does (same code, same bits, nothing stored) and then runs the geometry kernel's body on the new state, leaving ONE float2 per
 // pedestrian and slice in geo_next; every integrating prologue adds the previous launch's geo_prev rows to the force.  Vehicles that
 // move on the device are a third role (blocks behind the pair workgroups, a wave per vehicle): they write the NEXT launch's centres and
 // rings into the other half of a ping-pong while this launch's geometry workgroups read the current one.
-template <bool RAD, int NW, int SYS>
+template <bool RAD, int NW, bool Z3>
 struct FusedShared {                             // LDS of one pair-role workgroup
     float4 st[2 * GROUP];                        // the workgroup's pedestrians in the state the pairs are evaluated on: GX then GY
     float rad[2 * GROUP];
@@ -2044,16 +2045,22 @@ struct FusedShared {                             // LDS of one pair-role workgro
     int any;
     float2 fi[NW][WAVE];
     float2 fj[NW][WAVE];
-    float4 trav[SYS ? 4 : 1][2 * WAVE];          // SYS 1: the four tiles as travelling operands, each twice back to back
-    float radt[(SYS && RAD) ? 4 : 1][2 * WAVE];
+    float4 trav[4][2 * WAVE];                    // the four tiles as travelling operands, each twice back to back
+    float radt[RAD ? 4 : 1][2 * WAVE];
+    float2 stz[Z3 ? 2 * GROUP : 1];              // 3-D crowds: {z, vz} of the same pedestrians ...
+    float2 travz[Z3 ? 4 : 1][2 * WAVE];          // ... {z, lambda vz} as travelling operands
+    float qz[Z3 ? NW / 2 : 1][2 * GROUP];        // ... and the z components of the sums
+    float partz[Z3 ? 2 * GROUP : 1];
+    float fiz[Z3 ? NW : 1][WAVE];
+    float fjz[Z3 ? NW : 1][WAVE];
 };
 
-template <bool RAD, int NW, int SYS, bool GEO>   // NW waves per workgroup (8 or 16): 256 / NW systolic steps each
+template <bool RAD, int NW, bool Z3, bool GEO>   // NW waves per workgroup (8 or 16): 256 / NW systolic steps each
 __global__ __launch_bounds__(NW * WAVE, 8) void sfm_fused_tick_kernel(const TickArgs a, const FusedArgs f) {   // 8 waves per SIMD: two 16-wave (four 8-wave) workgroups per CU
     constexpr int PARTS = NW / 2;                // the slab rows are split over this many 128-thread parts
     constexpr int SPW = 4 * WAVE / NW;           // systolic steps per wave
     constexpr int D = NW / 8;                    // waves per diagonal tile
-    using Sh = FusedShared<RAD, NW, SYS>;
+    using Sh = FusedShared<RAD, NW, Z3>;
     constexpr size_t LDS = (GEO && sizeof(GeoShared<NW>) > sizeof(Sh)) ? sizeof(GeoShared<NW>) : sizeof(Sh);
     __shared__ __attribute__((aligned(16))) char smem[LDS];
     Sh& sh = *reinterpret_cast<Sh*>(smem);
@@ -2134,10 +2141,12 @@ __global__ __launch_bounds__(NW * WAVE, 8) void sfm_fused_tick_kernel(const Tick
     const int i = G * GROUP + (p & (GROUP - 1)); // < N_pad whenever the group exists (N_pad is a multiple of four tiles)
     const bool live = present && i < a.N;
     float4 st = make_float4(0.f, 0.f, 0.f, 0.f), o = st;
+    float2 stz = make_float2(0.f, 0.f);          // Z3: {z, vz}
     float2 geo_f = make_float2(0.f, 0.f);        // GEO: border + obstacle forces on the stored state, left by the previous launch
     uint32_t nd0 = 0, pid = 0;
     if (present && lower) {
         st = a.pk_cur[i];
+        if (Z3) stz = a.zv_cur[i];
         if (live && integrate) {
             o = f.own_cur[i];
             if (GEO) {
@@ -2151,7 +2160,7 @@ __global__ __launch_bounds__(NW * WAVE, 8) void sfm_fused_tick_kernel(const Tick
         if (RAD) {
             const float r_ = a.radius[i];
             sh.rad[p] = r_;
-            if (SYS) { sh.radt[(SYS && RAD) ? (p >> 6) : 0][p & (WAVE - 1)] = r_; sh.radt[(SYS && RAD) ? (p >> 6) : 0][(p & (WAVE - 1)) + WAVE] = r_; }
+            sh.radt[RAD ? (p >> 6) : 0][p & (WAVE - 1)] = r_; sh.radt[RAD ? (p >> 6) : 0][(p & (WAVE - 1)) + WAVE] = r_;
         }
     }
     if (tid == 0) sh.any = 0;
@@ -2161,56 +2170,87 @@ __global__ __launch_bounds__(NW * WAVE, 8) void sfm_fused_tick_kernel(const Tick
         const int Gq = (2 * pp < GROUP) ? GX : GY;
         const int i2 = Gq * GROUP + ((2 * pp) & (GROUP - 1));
         float4 acc4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        float2 accz = make_float2(0.f, 0.f);
         if (integrate && a.en_ped && Gq < n_g && i2 < a.N) {
             const float4* col = reinterpret_cast<const float4*>(f.slab_prev + i2);
+            const float2* colz = Z3 ? reinterpret_cast<const float2*>(f.slabz_prev + i2) : nullptr;
             const size_t stride4 = (size_t)a.N_pad / 2;
             const int per = (n_g + PARTS - 1) / PARTS;
             const int r1 = min(n_g, (part + 1) * per);
-            for (int r0 = part * per; r0 < r1; r0 += 8) {
-                float4 v[8];
+            if (!Z3) {
+                for (int r0 = part * per; r0 < r1; r0 += 8) {
+                    float4 v[8];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] = (r0 + k < r1) ? col[(size_t)(r0 + k) * stride4] : make_float4(0.f, 0.f, 0.f, 0.f);
-                acc4.x += ((v[0].x + v[1].x) + (v[2].x + v[3].x)) + ((v[4].x + v[5].x) + (v[6].x + v[7].x));
-                acc4.y += ((v[0].y + v[1].y) + (v[2].y + v[3].y)) + ((v[4].y + v[5].y) + (v[6].y + v[7].y));
-                acc4.z += ((v[0].z + v[1].z) + (v[2].z + v[3].z)) + ((v[4].z + v[5].z) + (v[6].z + v[7].z));
-                acc4.w += ((v[0].w + v[1].w) + (v[2].w + v[3].w)) + ((v[4].w + v[5].w) + (v[6].w + v[7].w));
+                    for (int k = 0; k < 8; ++k) v[k] = (r0 + k < r1) ? col[(size_t)(r0 + k) * stride4] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    acc4.x += ((v[0].x + v[1].x) + (v[2].x + v[3].x)) + ((v[4].x + v[5].x) + (v[6].x + v[7].x));
+                    acc4.y += ((v[0].y + v[1].y) + (v[2].y + v[3].y)) + ((v[4].y + v[5].y) + (v[6].y + v[7].y));
+                    acc4.z += ((v[0].z + v[1].z) + (v[2].z + v[3].z)) + ((v[4].z + v[5].z) + (v[6].z + v[7].z));
+                    acc4.w += ((v[0].w + v[1].w) + (v[2].w + v[3].w)) + ((v[4].w + v[5].w) + (v[6].w + v[7].w));
+                }
+            } else {
+                // (four rows in flight instead of eight: the z rows ride along and the registers are the same 64 per lane)
+                for (int r0 = part * per; r0 < r1; r0 += 4) {
+                    float4 v[4];
+                    float2 vz[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        v[k] = (r0 + k < r1) ? col[(size_t)(r0 + k) * stride4] : make_float4(0.f, 0.f, 0.f, 0.f);
+                        vz[k] = (r0 + k < r1) ? colz[(size_t)(r0 + k) * stride4] : make_float2(0.f, 0.f);
+                    }
+                    acc4.x += (v[0].x + v[1].x) + (v[2].x + v[3].x);
+                    acc4.y += (v[0].y + v[1].y) + (v[2].y + v[3].y);
+                    acc4.z += (v[0].z + v[1].z) + (v[2].z + v[3].z);
+                    acc4.w += (v[0].w + v[1].w) + (v[2].w + v[3].w);
+                    accz.x += (vz[0].x + vz[1].x) + (vz[2].x + vz[3].x);
+                    accz.y += (vz[0].y + vz[1].y) + (vz[2].y + vz[3].y);
+                }
             }
         }
         sh.q[part][2 * pp] = make_float2(acc4.x, acc4.y);
         sh.q[part][2 * pp + 1] = make_float2(acc4.z, acc4.w);
+        if (Z3) { sh.qz[Z3 ? part : 0][2 * pp] = accz.x; sh.qz[Z3 ? part : 0][2 * pp + 1] = accz.y; }
     }
     __syncthreads();
     // the arithmetic of sfm_sym_epilogue_kernel without border / obstacle forces (pedestrian_simulation.py:57-83,
     // forces.py:40-52): acceleration towards the waypoint, capped velocity, position, arrival -> next waypoint
-    auto put_state = [&](const float4 ns) {       // pedestrian slot p of the workgroup in the state the pairs are evaluated on
+    auto put_state = [&](const float4 ns, const float2 nsz) {   // pedestrian slot p of the workgroup in the state the pairs are evaluated on
         sh.st[p] = ns;
-        if (SYS) {
-            const float4 t = make_float4(ns.x, ns.y, a.ped.lam * ns.z, a.ped.lam * ns.w);
-            sh.trav[p >> 6][p & (WAVE - 1)] = t;
-            sh.trav[p >> 6][(p & (WAVE - 1)) + WAVE] = t;
+        const float4 t = make_float4(ns.x, ns.y, a.ped.lam * ns.z, a.ped.lam * ns.w);
+        sh.trav[p >> 6][p & (WAVE - 1)] = t;
+        sh.trav[p >> 6][(p & (WAVE - 1)) + WAVE] = t;
+        if (Z3) {
+            sh.stz[Z3 ? p : 0] = nsz;
+            const float2 tz = make_float2(nsz.x, a.ped.lam * nsz.y);
+            sh.travz[Z3 ? (p >> 6) : 0][p & (WAVE - 1)] = tz;
+            sh.travz[Z3 ? (p >> 6) : 0][(p & (WAVE - 1)) + WAVE] = tz;
         }
     };
-    auto finish = [&](const float2 g) {
+    auto finish = [&](const float2 g, const float gz) {
         const float fpx = a.en_ped ? a.ped.negA * g.x : 0.f, fpy = a.en_ped ? a.ped.negA * g.y : 0.f;
+        const float fpz = (Z3 && a.en_ped) ? a.ped.negA * gz : 0.f;
         const float x = st.x, y = st.y, vx = st.z, vy = st.w, ts = o.z;
+        const float z = stz.x, vz = stz.y;
         float wx = o.x, wy = o.y;
-        float fax = 0.f, fay = 0.f;
+        float fax = 0.f, fay = 0.f, faz = 0.f;
         if (a.en_acc) {
             const float tx_ = wx - x, ty_ = wy - y;
             const float nrm = sqrtf(fmaf(tx_, tx_, ty_ * ty_));
             const float inv = (nrm == 0.0f) ? 1.0f : 1.0f / nrm;
             fax = (ts * (tx_ * inv) - vx) * a.inv_tau;
             fay = (ts * (ty_ * inv) - vy) * a.inv_tau;
+            if (Z3) faz = (0.0f - vz) * a.inv_tau;
         }
         const float Fx = (fax + fpx) + geo_f.x, Fy = (fay + fpy) + geo_f.y;   // forces.py order: acceleration, pedestrian, border + obstacles
-        float nvx = fmaf(a.dt, Fx, vx), nvy = fmaf(a.dt, Fy, vy);
-        float sp = sqrtf(fmaf(nvx, nvx, nvy * nvy));
+        const float Fz = faz + fpz;
+        float nvx = fmaf(a.dt, Fx, vx), nvy = fmaf(a.dt, Fy, vy), nvz = Z3 ? fmaf(a.dt, Fz, vz) : 0.f;
+        float sp = Z3 ? sqrtf(fmaf(nvx, nvx, fmaf(nvy, nvy, nvz * nvz))) : sqrtf(fmaf(nvx, nvx, nvy * nvy));
         sp = (sp == 0.0f) ? 1.0f : sp;
         const float fac = fminf(1.0f, (ts * a.max_speed_factor) / sp);
-        nvx *= fac; nvy *= fac;
-        float nx = x, ny = y;
-        if (a.flags & 1u) { nx = fmaf(a.dt, nvx, x); ny = fmaf(a.dt, nvy, y); }
+        nvx *= fac; nvy *= fac; nvz *= fac;
+        float nx = x, ny = y, nz = z;
+        if (a.flags & 1u) { nx = fmaf(a.dt, nvx, x); ny = fmaf(a.dt, nvy, y); if (Z3) nz = fmaf(a.dt, nvz, z); }
         const float4 ns = make_float4(nx, ny, nvx, nvy);
+        const float2 nsz = make_float2(nz, nvz);
         if (diag_item) {                                             // this workgroup stores the group
             if (a.flags & 2u) {
                 const float ax_ = wx - x, ay_ = wy - y;
@@ -2223,19 +2263,21 @@ __global__ __launch_bounds__(NW * WAVE, 8) void sfm_fused_tick_kernel(const Tick
             }
             f.own_next[i] = make_float4(wx, wy, o.z, o.w);
             a.pk_next[i] = ns;
+            if (Z3) a.zv_next[i] = nsz;
         }
-        put_state(ns);
+        put_state(ns, nsz);
     };
     bool bad = false;
     if (lower && present) {
         if (integrate && live) {
             float2 g = sh.q[0][p];
+            float gz = Z3 ? sh.qz[0][p] : 0.f;
 #pragma unroll
-            for (int k = 1; k < PARTS; ++k) { const float2 q = sh.q[k][p]; g.x += q.x; g.y += q.y; }
-            bad = a.en_ped && (!(fabsf(g.x) < __builtin_inff()) || !(fabsf(g.y) < __builtin_inff()));
-            if (bad) sh.any = 1; else finish(g);
+            for (int k = 1; k < PARTS; ++k) { const float2 q = sh.q[k][p]; g.x += q.x; g.y += q.y; if (Z3) gz += sh.qz[Z3 ? k : 0][p]; }
+            bad = a.en_ped && (!(fabsf(g.x) < __builtin_inff()) || !(fabsf(g.y) < __builtin_inff()) || (Z3 && !(fabsf(gz) < __builtin_inff())));
+            if (bad) sh.any = 1; else finish(g, gz);
         } else {
-            put_state(st);                                           // ghosts, and the first launch of a run: as stored
+            put_state(st, stz);                                      // ghosts, and the first launch of a run: as stored
         }
     }
     if (lower) sh.badrow[p] = bad ? 1 : 0;
@@ -2250,23 +2292,29 @@ __global__ __launch_bounds__(NW * WAVE, 8) void sfm_fused_tick_kernel(const Tick
             const int ip = Gq * GROUP + (q & (GROUP - 1));
             const float4 si = a.pk_cur[ip];
             const float xi = uniform(si.x), yi = uniform(si.y), vxi = uniform(si.z), vyi = uniform(si.w);
-            float gx = 0.f, gy = 0.f;
+            float zi = 0.f, vzi = 0.f;
+            if (Z3) { const float2 sz = a.zv_cur[ip]; zi = uniform(sz.x); vzi = uniform(sz.y); }
+            float gx = 0.f, gy = 0.f, gz = 0.f;
             for (int j0 = 0; j0 < N; j0 += WAVE) {
                 const int j = j0 + lane;
                 const float4 pj = a.pk_cur[min(j, N - 1)];
+                float2 pz = make_float2(0.f, 0.f);
+                if (Z3) pz = a.zv_cur[min(j, N - 1)];
                 float cx = 0.f, cy = 0.f, cz = 0.f, rinv;
-                moussaid<false, RAD, true>(a.ped, pj.x - xi, pj.y - yi, 0.f, vxi - pj.z, vyi - pj.w, 0.f,
-                                           RAD ? a.radius[ip] + a.radius[min(j, N - 1)] : 0.f, cx, cy, cz, rinv);
+                moussaid<Z3, RAD, true>(a.ped, pj.x - xi, pj.y - yi, pz.x - zi, vxi - pj.z, vyi - pj.w, vzi - pz.y,
+                                        RAD ? a.radius[ip] + a.radius[min(j, N - 1)] : 0.f, cx, cy, cz, rinv);
                 const bool valid = (j < N) & (j != ip);
                 gx += valid ? cx : 0.f;
                 gy += valid ? cy : 0.f;
+                if (Z3) gz += valid ? cz : 0.f;
             }
             gx = wave_sum(gx);
             gy = wave_sum(gy);
-            if (lane == 0) sh.part[q] = make_float2(gx, gy);
+            if (Z3) gz = wave_sum(gz);
+            if (lane == 0) { sh.part[q] = make_float2(gx, gy); if (Z3) sh.partz[Z3 ? q : 0] = gz; }
         }
         __syncthreads();
-        if (bad) finish(sh.part[p]);
+        if (bad) finish(sh.part[p], Z3 ? sh.partz[Z3 ? p : 0] : 0.f);
         __syncthreads();
     }
 
@@ -2317,102 +2365,90 @@ __global__ __launch_bounds__(NW * WAVE, 8) void sfm_fused_tick_kernel(const Tick
         sig0 = (wave % (NW / 4)) * SPW;
         work = 2 * GX + (q >> 1) < n_t && 2 * GY + (q & 1) < n_t;
     }
-    float fxi = 0.f, fyi = 0.f, fxj = 0.f, fyj = 0.f;
+    float fxi = 0.f, fyi = 0.f, fxj = 0.f, fyj = 0.f, fzi = 0.f, fzj = 0.f;
     int i_end_loc = lane;
-    if (work && SYS) {
+    if (work) {
         const IxConst& c = a.ped;
         const float4 pj = sh.st[ib + lane];
         const float ujx = c.lam * pj.z, ujy = c.lam * pj.w;
         float rj = 0.f;
         if (RAD) rj = sh.rad[ib + lane];
+        float zj = 0.f, ujz = 0.f;
+        if (Z3) { const float2 qz = sh.stz[Z3 ? ib + lane : 0]; zj = qz.x; ujz = c.lam * qz.y; }
         // step s meets pedestrian (lane + sig0 + s) mod 64 of the travelling tile: slot lane + sig0 + s of the doubled image
-        const float4* trav = &sh.trav[SYS ? (ia >> 6) : 0][lane + sig0];
-        const float* radt = &sh.radt[(SYS && RAD) ? (ia >> 6) : 0][lane + sig0];
+        const float4* trav = &sh.trav[ia >> 6][lane + sig0];
+        const float* radt = &sh.radt[RAD ? (ia >> 6) : 0][lane + sig0];
+        const float2* travz = &sh.travz[Z3 ? (ia >> 6) : 0][lane + sig0];
         // sigma = 32 on a diagonal tile meets every unordered pair {l, l+32} in BOTH lanes: one-sided there
         const bool tail_one_sided = diag && (sig0 + SPW - 1 == 32);  // uniform
         float4 T = trav[0];
         float ri = RAD ? radt[0] : 0.f;
+        float2 Tz = make_float2(0.f, 0.f);
+        if (Z3) Tz = travz[0];
 #pragma unroll
         for (int s_ = 0; s_ < SPW; ++s_) {
             float4 Tn = T;
             float rin = ri;
-            if (s_ + 1 < SPW) { Tn = trav[s_ + 1]; if (RAD) rin = radt[s_ + 1]; }      // the next step's operand is in flight during this one
+            float2 Tzn = Tz;
+            if (s_ + 1 < SPW) { Tn = trav[s_ + 1]; if (RAD) rin = radt[s_ + 1]; if (Z3) Tzn = travz[s_ + 1]; }   // the next step's operand is in flight during this one
             __builtin_amdgcn_sched_barrier(0);       // (... so its read is issued here, not where the scheduler would sink it to)
             const float dx = pj.x - T.x, dy = pj.y - T.y;
-            const float d2 = fmaf(dx, dx, dy * dy);
-            float cx, cy;
-            moussaid_planar<RAD, false>(c, dx, dy, d2, T.z - ujx, T.w - ujy, RAD ? ri + rj : 0.f, cx, cy);
+            float cx, cy, cz = 0.f;
+            if (Z3) {
+                const float dz = zj - Tz.x;
+                moussaid_spatial<RAD, false>(c, dx, dy, dz, fmaf(dx, dx, fmaf(dy, dy, dz * dz)), T.z - ujx, T.w - ujy, Tz.y - ujz, RAD ? ri + rj : 0.f, cx, cy, cz);
+            } else {
+                moussaid_planar<RAD, false>(c, dx, dy, fmaf(dx, dx, dy * dy), T.z - ujx, T.w - ujy, RAD ? ri + rj : 0.f, cx, cy);
+            }
             // the sums of the pedestrian this lane has just met were in lane + 1 a step ago: rotation and add in one instruction
             fxi = rot_in(fxi) + cx;
             fyi = rot_in(fyi) + cy;
-            if (s_ + 1 < SPW || !tail_one_sided) { fxj -= cx; fyj -= cy; }
+            if (Z3) fzi = rot_in(fzi) + cz;
+            if (s_ + 1 < SPW || !tail_one_sided) { fxj -= cx; fyj -= cy; if (Z3) fzj -= cz; }
             T = Tn;
             ri = rin;
+            Tz = Tzn;
             __builtin_amdgcn_sched_barrier(0);       // steps are not interleaved: eight waves per SIMD hide a step's chain
         }
         i_end_loc = (lane + sig0 + SPW - 1) & (WAVE - 1);
     }
-    if (work && !SYS) {
-        const float4 pj = sh.st[ib + lane];
-        const int i_loc0 = (lane + f.dir * sig0) & (WAVE - 1);
-        const float4 pi0 = sh.st[ia + i_loc0];
-        float rj = 0.f, ri = 0.f;
-        if (RAD) { rj = sh.rad[ib + lane]; ri = sh.rad[ia + i_loc0]; }
-        const IxConst& c = a.ped;
-        float xi = pi0.x, yi = pi0.y, uxi = c.lam * pi0.z, uyi = c.lam * pi0.w;
-        const float ujx = c.lam * pj.z, ujy = c.lam * pj.w;
-        auto step = [&](bool both) {
-            const float dx = pj.x - xi, dy = pj.y - yi;
-            const float d2 = fmaf(dx, dx, dy * dy);
-            float cx, cy;
-            moussaid_planar<RAD, false>(c, dx, dy, d2, uxi - ujx, uyi - ujy, RAD ? ri + rj : 0.f, cx, cy);
-            fxi += cx;
-            fyi += cy;
-            if (both) { fxj -= cx; fyj -= cy; }
-            xi = rot1(xi); yi = rot1(yi); uxi = rot1(uxi); uyi = rot1(uyi);
-            if (RAD) ri = rot1(ri);
-            fxi = rot1(fxi); fyi = rot1(fyi);
-        };
-        // sigma = 32 on a diagonal tile meets every unordered pair {l, l+32} in BOTH lanes: one-sided there
-        const bool tail_one_sided = diag && (sig0 + SPW - 1 == 32);  // uniform
-#pragma unroll 1
-        for (int s = 0; s < SPW - 1; ++s) step(true);
-        if (tail_one_sided) step(false); else step(true);
-        i_end_loc = (lane + f.dir * (sig0 + SPW)) & (WAVE - 1);
-    }
     sh.fi[wave][i_end_loc] = make_float2(fxi, fyi);
     sh.fj[wave][lane] = make_float2(fxj, fyj);
+    if (Z3) { sh.fiz[Z3 ? wave : 0][i_end_loc] = fzi; sh.fjz[Z3 ? wave : 0][lane] = fzj; }
     __syncthreads();
     if (!lower || !present) return;
     const int tl = (p >> 6) & 1, l = lane;       // tile of the group, pedestrian of the tile
-    auto fi = [&](int w) { return sh.fi[w][l]; };   // travelling-side sum of wave w for pedestrian l of its travelling tile
-    float2 r = make_float2(0.f, 0.f);
+    // sums of wave w for pedestrian l of its travelling / resident tile, z in the third component
+    auto fi = [&](int w) { const float2 v = sh.fi[w][l]; return make_float3(v.x, v.y, Z3 ? sh.fiz[Z3 ? w : 0][l] : 0.f); };
+    auto fj = [&](int w) { const float2 v = sh.fj[w][l]; return make_float3(v.x, v.y, Z3 ? sh.fjz[Z3 ? w : 0][l] : 0.f); };
+    float3 r = make_float3(0.f, 0.f, 0.f);
     int row;                                     // partner group = slab row
     if (diag_item) {
         const int w0 = (p < GROUP) ? 0 : NW / 2;
 #pragma unroll
         for (int k = 0; k < D; ++k) {            // the tile's own diagonal item: both sides are this tile
-            const float2 u = fi(w0 + tl * D + k), v = sh.fj[w0 + tl * D + k][l];
-            r.x += u.x + v.x; r.y += u.y + v.y;
+            const float3 u = fi(w0 + tl * D + k), v = fj(w0 + tl * D + k);
+            r.x += u.x + v.x; r.y += u.y + v.y; r.z += u.z + v.z;
         }
 #pragma unroll
         for (int k = 0; k < 2 * D; ++k) {        // the other tile of the group
-            const float2 u = tl ? sh.fj[w0 + 2 * D + k][l] : fi(w0 + 2 * D + k);
-            r.x += u.x; r.y += u.y;
+            const float3 u = tl ? fj(w0 + 2 * D + k) : fi(w0 + 2 * D + k);
+            r.x += u.x; r.y += u.y; r.z += u.z;
         }
         row = G;
     } else if (p < GROUP) {                      // force on GX's pedestrians from GY: the travelling sides
 #pragma unroll
-        for (int k = 0; k < NW / 2; ++k) { const float2 u = fi(tl * (NW / 2) + k); r.x += u.x; r.y += u.y; }
+        for (int k = 0; k < NW / 2; ++k) { const float3 u = fi(tl * (NW / 2) + k); r.x += u.x; r.y += u.y; r.z += u.z; }
         row = GY;
     } else {                                     // force on GY's pedestrians from GX: the resident sides
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int k = 0; k < NW / 4; ++k) { const float2 u = sh.fj[(2 * h + tl) * (NW / 4) + k][l]; r.x += u.x; r.y += u.y; }
+            for (int k = 0; k < NW / 4; ++k) { const float3 u = fj((2 * h + tl) * (NW / 4) + k); r.x += u.x; r.y += u.y; r.z += u.z; }
         row = GX;
     }
-    f.slab_next[(size_t)row * a.N_pad + i] = r;
+    f.slab_next[(size_t)row * a.N_pad + i] = make_float2(r.x, r.y);
+    if (Z3) f.slabz_next[(size_t)row * a.N_pad + i] = r.z;
 }
 
 // Dynamic obstacles on the device (obstacles.py:297-329 without the simulator): one wave per vehicle moves the centre
@@ -2621,24 +2657,24 @@ hipError_t launch_sym_epilogue(bool rad, const TickArgs& a, const SymArgs& sa, h
 // number of pair workgroups of the fused tick: diagonal items, full shifts, the half shift of an even n_g
 int fused_pair_workgroups(int n_g) { return (n_g + 1) / 2 + n_g * ((n_g - 1) / 2) + ((n_g & 1) ? 0 : n_g / 2); }
 
-template <bool RAD, int NW, int SYS>
-static void launch_fused_t(dim3 grid, bool geo, const TickArgs& a, const FusedArgs& f, hipStream_t st) {
-    if (geo) hipLaunchKernelGGL((sfm_fused_tick_kernel<RAD, NW, SYS, true>), grid, dim3(NW * WAVE), 0, st, a, f);
-    else hipLaunchKernelGGL((sfm_fused_tick_kernel<RAD, NW, SYS, false>), grid, dim3(NW * WAVE), 0, st, a, f);
+template <bool RAD, int NW>
+static void launch_fused_t(dim3 grid, bool geo, bool z3, const TickArgs& a, const FusedArgs& f, hipStream_t st) {
+    if (z3) {
+        if (geo) hipLaunchKernelGGL((sfm_fused_tick_kernel<RAD, NW, true, true>), grid, dim3(NW * WAVE), 0, st, a, f);
+        else hipLaunchKernelGGL((sfm_fused_tick_kernel<RAD, NW, true, false>), grid, dim3(NW * WAVE), 0, st, a, f);
+    } else {
+        if (geo) hipLaunchKernelGGL((sfm_fused_tick_kernel<RAD, NW, false, true>), grid, dim3(NW * WAVE), 0, st, a, f);
+        else hipLaunchKernelGGL((sfm_fused_tick_kernel<RAD, NW, false, false>), grid, dim3(NW * WAVE), 0, st, a, f);
+    }
 }
 
-hipError_t launch_fused_tick(bool rad, const TickArgs& a, const FusedArgs& f, hipStream_t st, int nw, int sys) {
+hipError_t launch_fused_tick(bool rad, const TickArgs& a, const FusedArgs& f, hipStream_t st, int nw) {
     if (a.N <= 1 || f.n_g < 2) return hipErrorInvalidValue;
-    const bool geo = f.n_geo_wg > 0;
+    const bool geo = f.n_geo_wg > 0, z3 = f.slabz_next != nullptr;
     const int n_adv = (geo && a.adv.M > 0) ? (a.adv.M + nw - 1) / nw : 0;
     const dim3 grid(f.n_geo_wg + f.n_pair_wg + n_adv);
-    if (nw == 8) {
-        if (sys == 0) { if (rad) launch_fused_t<true, 8, 0>(grid, geo, a, f, st); else launch_fused_t<false, 8, 0>(grid, geo, a, f, st); }
-        else { if (rad) launch_fused_t<true, 8, 1>(grid, geo, a, f, st); else launch_fused_t<false, 8, 1>(grid, geo, a, f, st); }
-    } else {
-        if (sys == 0) { if (rad) launch_fused_t<true, 16, 0>(grid, geo, a, f, st); else launch_fused_t<false, 16, 0>(grid, geo, a, f, st); }
-        else { if (rad) launch_fused_t<true, 16, 1>(grid, geo, a, f, st); else launch_fused_t<false, 16, 1>(grid, geo, a, f, st); }
-    }
+    if (nw == 8) { if (rad) launch_fused_t<true, 8>(grid, geo, z3, a, f, st); else launch_fused_t<false, 8>(grid, geo, z3, a, f, st); }
+    else { if (rad) launch_fused_t<true, 16>(grid, geo, z3, a, f, st); else launch_fused_t<false, 16>(grid, geo, z3, a, f, st); }
     return hipGetLastError();
 }
 

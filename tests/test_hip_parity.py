@@ -792,7 +792,8 @@ def _fused_resync_rounds(eng, sc, prm, n_ticks, row_blocks, seed, world_side, th
             sl = slice(r[0], r[1])
             worst_v = max(worst_v, P.check_velocity(dvel[sl], v_new, expo, 0.05))
             x_new = loc[sl] + 0.05 * v_new
-            x_new[:, 2] = loc[sl, 2]
+            if eng.planar:
+                x_new[:, 2] = loc[sl, 2]
             # a pedestrian within fp32 noise of a discontinuity moves by dt * dt * exposure at most
             allow = 1e-6 * np.maximum(1.0, np.abs(x_new).max(axis=1)) + 0.05 * 0.05 * expo * 1.001
             err = np.abs(dloc[sl] - x_new).max(axis=1)
@@ -815,15 +816,18 @@ def _fused_resync_rounds(eng, sc, prm, n_ticks, row_blocks, seed, world_side, th
     return variant, worst_v, worst_x, int(draws.sum())
 
 
-@pytest.mark.parametrize("n,use_radius,coincide", [(256, False, False), (300, True, False), (1000, False, True), (4160, False, False)])
-def test_fused_tick_pinned_to_the_oracle(n, use_radius, coincide, monkeypatch):
+@pytest.mark.parametrize("n,use_radius,coincide,z_spread", [(256, False, False, 0.0), (300, True, False, 0.0), (1000, False, True, 0.0), (4160, False, False, 0.0),
+                                                            (300, True, False, 1.5), (1000, False, True, 1.5), (4096, False, False, 1.5)])
+def test_fused_tick_pinned_to_the_oracle(n, use_radius, coincide, z_spread, monkeypatch):
     """sfm_fused_tick_kernel -- the kernel bench.py times on c2 -- against the ORACLE directly, re-synchronised every tick
     (round-2 verdict item 1): whole and ragged tiles, odd group counts, use_ped_radius, a coincident pair (NaN in the fast body,
     recomputed with the exact one), with waypoint redraws.  Tolerances: v' 1e-5 relative per pedestrian, x' 1e-6."""
-    sc = scenarios.make_scenario(n, 8800 + n, density=0.25 if use_radius else 1.0)
+    sc = scenarios.make_scenario(n, 8800 + n, density=0.25 if use_radius else 1.0, z_spread=z_spread)
     if coincide:
         sc.loc[n // 2] = sc.loc[n // 2 + 70]                  # two pedestrians of different tiles at the same place
         sc.loc[5] = sc.loc[6]                                 # ... and two of the same tile (different velocities: finite)
+        if z_spread:                                          # 3-D: above one another instead (e_xy = 0: the 3-D body's NaN signal)
+            sc.loc[n // 2, 2] = np.float32(sc.loc[n // 2, 2] + 0.6); sc.loc[5, 2] = np.float32(sc.loc[5, 2] - 0.4)
     cfg = default_sfm_config(("acceleration_force", "pedestrian_force"))
     cfg["use_ped_radius"] = use_radius
     prm = O.OracleParams.from_config(cfg)
@@ -834,7 +838,8 @@ def test_fused_tick_pinned_to_the_oracle(n, use_radius, coincide, monkeypatch):
         eng.upload_state(sc.loc, sc.vel, sc.waypoint, sc.target_speed, sc.radius, None)
         eng.set_waypoint_stream(sc.seed, side, 2.0)
         variant, wv, wx, nd = _fused_resync_rounds(eng, sc, prm, 8, ((0, n),), sc.seed, side)
-        print(f"\nfused tick vs oracle, N={n}: {variant}  worst v' rel {wv:.3g}  worst x' rel {wx:.3g}  redraws {nd}")
+        assert eng.planar == (z_spread == 0.0)
+        print(f"\nfused tick vs oracle, N={n}{' 3-D' if z_spread else ''}: {variant}  worst v' rel {wv:.3g}  worst x' rel {wx:.3g}  redraws {nd}")
     finally:
         eng.close()
 
@@ -858,9 +863,10 @@ def test_fused_tick_pinned_to_the_oracle_at_c2(monkeypatch):
         eng.close()
 
 
-def _geo_scenario(n, seed):
+def _geo_scenario(n, seed, z_spread=0.0):
     """A mid-sized crowd with all five forces: borders, static obstacles, vehicles that move on the device."""
-    return scenarios.make_scenario(n, seed, n_borders=max(24, n // 16), n_static=max(12, n // 128), n_dynamic=6, border_len=(5.0, 25.0))
+    return scenarios.make_scenario(n, seed, n_borders=max(24, n // 16), n_static=max(12, n // 128), n_dynamic=6, border_len=(5.0, 25.0),
+                                   z_spread=z_spread)
 
 
 def _geo_engine(sc, cfg):
@@ -873,13 +879,13 @@ def _geo_engine(sc, cfg):
     return eng
 
 
-@pytest.mark.parametrize("n", [512, 1000, 2048, 4096])
-def test_fused_tick_with_border_and_obstacle_forces_pinned_to_the_oracle(n, monkeypatch):
+@pytest.mark.parametrize("n,z_spread", [(512, 0.0), (1000, 0.0), (2048, 0.0), (4096, 0.0), (1000, 1.5), (4096, 1.5)])
+def test_fused_tick_with_border_and_obstacle_forces_pinned_to_the_oracle(n, z_spread, monkeypatch):
     """Round 3: crowds below the list cutoff WITH border / obstacle forces take the fused tick too -- geometry workgroups are a
     second role of sfm_fused_tick_kernel, vehicles that move on the device a third (forces.py:138-283, obstacles.py:297-329).
     Every tick re-synchronised against the oracle (v' 1e-5, x' 1e-6), the device's vehicles against the host twin bit for bit;
     N = 4096 runs the 8-wave form of the launch (pair + geometry workgroups do not fit in 512 slots of 16 waves)."""
-    sc = _geo_scenario(n, 6100 + n)
+    sc = _geo_scenario(n, 6100 + n, z_spread)
     cfg = default_sfm_config(scenarios.ALL_FORCES)
     prm = O.OracleParams.from_config(cfg)
     monkeypatch.setenv("SFM_FUSED", "2")                      # a single sfm_run(1) takes the fused tick (launch in front + one integrating launch)
@@ -904,7 +910,8 @@ def test_fused_tick_with_border_and_obstacle_forces_pinned_to_the_oracle(n, monk
                 P.check_velocity_conditioned(dvel[sl], v_new, expo, absum, 0.05)
                 worst = max(worst, float(np.max(np.linalg.norm(dvel[sl] - v_new, axis=1) / np.maximum(np.linalg.norm(v_new, axis=1), 1e-12))))
                 x_new = loc[sl] + 0.05 * v_new
-                x_new[:, 2] = loc[sl, 2]
+                if eng.planar:
+                    x_new[:, 2] = loc[sl, 2]
                 allow = 1e-6 * np.maximum(1.0, np.abs(x_new).max(axis=1)) + 0.05 * (1e-5 * 0.05 * absum + 0.05 * expo * 1.001)
                 assert (np.abs(dloc[sl] - x_new).max(axis=1) <= allow).all(), f"x' at tick {k}"
             loc, vel = dloc, dvel
@@ -915,13 +922,13 @@ def test_fused_tick_with_border_and_obstacle_forces_pinned_to_the_oracle(n, monk
         eng.close()
 
 
-@pytest.mark.parametrize("n,use_radius", [(700, False), (2500, True), (4096, False)])
-def test_fused_run_with_border_and_obstacle_forces_matches_the_two_launch_tick(n, use_radius, monkeypatch):
+@pytest.mark.parametrize("n,use_radius,z_spread", [(700, False, 0.0), (2500, True, 0.0), (4096, False, 0.0), (2500, False, 1.5), (4096, True, 1.5)])
+def test_fused_run_with_border_and_obstacle_forces_matches_the_two_launch_tick(n, use_radius, z_spread, monkeypatch):
     """The CARRIED path of the same: inside one sfm_run the geometry workgroups of launch k evaluate the state launch k has just
     integrated, against the vehicles launch k-1 moved on (ping-pong), across device re-packs (every 5 ticks here: each followed by a
     launch in front).  14 ticks agree with the two-launch tick (pair + geometry launch, epilogue launch) to rounding drift, the
     vehicles end in the same place bit for bit, two runs are bit-identical, and split runs carry on."""
-    sc = _geo_scenario(n, 7300 + n)
+    sc = _geo_scenario(n, 7300 + n, z_spread)
     cfg = default_sfm_config(scenarios.ALL_FORCES)
     cfg["use_ped_radius"] = use_radius
     monkeypatch.setenv("SFM_RESORT_EVERY", "5")
