@@ -23,7 +23,6 @@ hipError_t launch_sym_epilogue(bool rad, const TickArgs& a, const SymArgs& sa, h
 hipError_t launch_fused_tick(bool rad, const TickArgs& a, const FusedArgs& f, hipStream_t st, int waves);
 int fused_pair_workgroups(int n_g);
 hipError_t launch_sym_pair_geo(bool rad, const TickArgs& a, const SymArgs& sa, hipStream_t st);
-hipError_t launch_schedule(const int* cost, int n_t, uint32_t* work, int* count, hipStream_t st);
 int sym_item_count(int n_t);
 hipError_t launch_strip_bounds(const float4* box, const float* vmax, int n_t, int tps, int n_strips, float4* sbox, float* svmax,
                                hipStream_t st);
@@ -100,7 +99,7 @@ struct SfmHandle {
     int dpp_dir = 0;
     int sym_mode = -1;                     // SFM_SYM: 0 off, 1 on when eligible, -1 auto
     // tile-granular cutoff of provably negligible pedestrian pairs
-    float4* tile_box = nullptr;            // [2][n_t]: the lite cutoff ping-pongs (epilogue k writes the boxes of tick k+1)
+    float4* tile_box = nullptr;            // [2][n_t]: ping-pong (the epilogue of tick k writes the boxes of tick k+1)
     float* tile_vmax = nullptr;
     char* up_stage = nullptr;              // pinned host block sfm_upload_state assembles the rows in: one async copy to its
     size_t up_stage_cap = 0;               // device twin, one kernel spreads it over the arrays
@@ -119,8 +118,7 @@ struct SfmHandle {
     uint32_t* work = nullptr;
     int* work_count = nullptr;
     size_t work_cap = 0;
-    int cut_mode = -1;                     // SFM_CUTOFF: 0 off, 1 list-based, 2 lite (+ dealt item order), -1 auto (list-based for N >= 8192)
-    int sched_mode = -1;                   // SFM_SCHED=0: lite cutoff without the cost-balanced item order (A/B)
+    int cut_mode = -1;                     // SFM_CUTOFF: 0 off, 1 on, -1 auto (on for N >= 8192)
     unsigned long long* stamps = nullptr;  // SFM_STAMPS diagnostic: per-workgroup timestamps of the symmetric pair kernel
     unsigned long long* geo_stamps = nullptr;   // SFM_GEO_STAMPS diagnostic: per-workgroup phase stamps of the geometry kernel
     // spatial reordering: row s holds the caller's pedestrian perm[s] (strips in x, each sorted by y: sfm_reorder.hip), so the 64-tiles
@@ -172,10 +170,6 @@ struct SfmHandle {
     bool carry_ok = false;
     int carry_sl = 0;
     bool last_list = false;                // the last symmetric tick ran from the tile-pair list (cutoff on)
-    // scheduled lite cutoff (mid-sized whole crowds): per-item step counts of the last tick and whether `work` holds a dealt order
-    int* cost = nullptr;
-    size_t cost_cap = 0;
-    bool sched_valid = false, last_sched = false;
 
     uint32_t seed = 0;
     float world_side = 0.f, arrive_thr = 2.0f;
@@ -358,8 +352,6 @@ int sfm_create(const SfmParams* params, int device_id, SfmHandle** out) {
     if (ov) h->fused_geo_mode = atoi(ov);
     ov = exp_env("SFM_FUSED_GEO_SLICES");
     if (ov) h->fused_geo_slices = atoi(ov);
-    ov = exp_env("SFM_SCHED");
-    if (ov) h->sched_mode = atoi(ov);
     ov = getenv("SFM_REORDER");
     if (ov) h->reorder_mode = atoi(ov);
     ov = getenv("SFM_GEO_SLICES");
@@ -447,7 +439,6 @@ int sfm_destroy(SfmHandle* h) {
     if (h->strip_vmax) hipFree(h->strip_vmax);
     if (h->work) hipFree(h->work);
     if (h->work_count) hipFree(h->work_count);
-    if (h->cost) hipFree(h->cost);
     if (h->work2) hipFree(h->work2);
     free_geo(h->borders); free_geo(h->statics); free_geo(h->dynamics);
     if (h->aux) { hipStreamSynchronize(h->aux); hipStreamDestroy(h->aux); }
@@ -810,8 +801,6 @@ int sfm_upload_state(SfmHandle* h, int N, const float* x, const float* y, const 
         if (h->n_t < 65536 && items > h->work_cap) { HIP_TRY(h, dev_realloc(h->work, items)); h->work_cap = items; }
         if (!h->work_count) HIP_TRY(h, dev_realloc(h->work_count, (size_t)4));    // [0] list, [1] own-own list of a split tick, [2] copy of [0] left by a zeroing epilogue
         h->begin_done = false;
-        if (h->n_t <= 128 && items > h->cost_cap) { HIP_TRY(h, dev_realloc(h->cost, items)); h->cost_cap = items; }
-        h->sched_valid = false;
     }
     return SFM_OK;
 }
@@ -955,30 +944,16 @@ static void fill_args(SfmHandle* h, TickArgs& a, uint32_t flags) {
                        (h->dyn_boxes && (flags & SFM_TICK_INTEGRATE)) ? h->dynamics.K : 0, h->prm.step_length, 0};
     const bool cut = p.enabled[SFM_FORCE_PEDESTRIAN] && h->tile_box && h->N <= 64 * 64 * WAVE &&
                      (h->cut_mode == 1 || (h->cut_mode < 0 && h->N >= 8192)) && p.pedestrian.gamma > 0.f && p.pedestrian.lambda >= 0.f;
-    // "lite" cutoff (no work list): the pair kernel's workgroups test their own tile pair and the symmetric epilogue
-    // keeps the boxes current; needs the whole crowd on this handle and the symmetric path
-    const bool lite_ok = p.enabled[SFM_FORCE_PEDESTRIAN] && h->tile_box && !h->z3 && !h->rad && h->slab && h->i_begin == 0 &&
-                         h->i_end == h->N && h->sym_mode != 0 && p.pedestrian.gamma > 0.f && p.pedestrian.lambda >= 0.f;
-    // opt-in (SFM_CUTOFF=2), with the cost-balanced item order (SymArgs::cost) when N <= 8192.  Measured on c2 (N = 4096 in a
-    // 128 m square, round 2): the reach of a walking crowd is ~77 m, so only 16 % of the systolic steps are out of reach in the
-    // steady state; balanced, the pair kernel drops 15.5 -> 14.9 us while the tile boxes, the dealer and the periodic
-    // re-pack add 2.2 us to the tick.  Off by default below 8192 pedestrians.
-#ifdef SFM_EXPERIMENTS
-    const bool lite = lite_ok && !cut && h->cut_mode == 2;
-#else
-    const bool lite = false;                       // (the lite cutoff and its dealer: measured, not shipped -- experiments build only)
-    (void)lite_ok;
-#endif
-    a.tile_box = (cut || lite) ? h->tile_box + (size_t)h->box_cur * h->n_t : nullptr;
-    a.tile_vmax = (cut || lite) ? h->tile_vmax + (size_t)h->box_cur * h->n_t : nullptr;
-    // whole crowd on the symmetric path: the epilogue leaves the next tick's boxes (and, list cutoff, a zeroed list counter), so
-    // the next tick starts with its list kernel instead of a bounds kernel and a memset
-    // (the boxes do not depend on the radii -- cut_pad carries 2 r_max into every test -- so use_ped_radius crowds carry them too)
-    const bool carry = lite || (cut && (lite_ok || (h->rad && p.enabled[SFM_FORCE_PEDESTRIAN] && h->tile_box && !h->z3 && h->slab && h->i_begin == 0 &&
-                                                  h->i_end == h->N && h->sym_mode != 0)) && h->carry_mode != 0 && !h->fsm_on);
+    a.tile_box = cut ? h->tile_box + (size_t)h->box_cur * h->n_t : nullptr;
+    a.tile_vmax = cut ? h->tile_vmax + (size_t)h->box_cur * h->n_t : nullptr;
+    // whole crowd on the symmetric path: the epilogue leaves the next tick's boxes and a zeroed list counter, so the next tick starts
+    // with its list kernel instead of a bounds kernel and a memset (the boxes do not depend on the radii -- cut_pad carries 2 r_max
+    // into every test -- and a 3-D crowd's largest speed includes v_z)
+    // (a cutoff for crowds under 8192 -- workgroups testing their own tile pair, a cost-balanced deal of the items -- was built and
+    //  measured in round 2: on c2 it cost as much in boxes, dealer and re-packs as it saved in steps.  Removed in round 3)
+    const bool carry = cut && h->slab && h->i_begin == 0 && h->i_end == h->N && h->sym_mode != 0 && h->carry_mode != 0 && !h->fsm_on;
     a.tile_box_out = carry ? h->tile_box + (size_t)(h->box_cur ^ 1) * h->n_t : nullptr;
     a.tile_vmax_out = carry ? h->tile_vmax + (size_t)(h->box_cur ^ 1) * h->n_t : nullptr;
-    a.lite = lite ? 1 : 0;
     a.cut_scale = (float)((double)p.pedestrian.gamma * 41.0 * 0.6931471805599453 * 1.001);
     a.cut_pad = h->rad ? 2.0f * h->r_max * 1.001f : 0.f;
     if (h->fsm_on)
@@ -1028,7 +1003,6 @@ static int resort_rows(SfmHandle* h) {
     h->perm_stale = true;
     h->ticks_since_sort = 0;
     h->boxes_valid = false;
-    h->sched_valid = false;                        // the tiles are other pedestrians now: last tick's costs mean nothing
     return SFM_OK;
 }
 
@@ -1049,16 +1023,13 @@ static void strip_shape(const SfmHandle* h, int* tps, int* n_strips) {
     *n_strips = on ? (h->n_t + *tps - 1) / *tps : 0;
 }
 
-// the symmetric path's view of one tick: slab, tile-pair list (list cutoff) or boxes (lite cutoff), strips, own tile range
+// the symmetric path's view of one tick: slab, tile-pair list (cutoff on), strips, own tile range
 static SymArgs make_sym_args(const SfmHandle* h, const TickArgs& a, int tps, int n_strips, int debug_steps, unsigned long long* stamps) {
-    const bool lite = a.lite != 0;
-    const bool list = a.tile_box && !lite;
-    const bool sched = lite && h->cost && h->sched_mode != 0 && (size_t)h->n_t * (size_t)(h->n_t / 2 + 1) <= h->cost_cap;
-    return SymArgs{h->slab, h->z3 ? h->slabz : nullptr, h->n_t, slab_stride(h->n_t), h->dpp_dir, debug_steps,
-                   (list || sched) ? h->work : nullptr, (list || sched) ? h->work_count : nullptr, lite ? a.tile_box : nullptr,
-                   (lite || list) ? a.tile_vmax : nullptr,
+    const bool list = a.tile_box != nullptr;
+    return SymArgs{h->slab, h->z3 ? h->slabz : nullptr, h->n_t, slab_stride(h->n_t), debug_steps,
+                   list ? h->work : nullptr, list ? h->work_count : nullptr, list ? a.tile_vmax : nullptr,
                    a.cut_scale, a.cut_pad, stamps, h->strip_box, h->strip_vmax, tps, n_strips,
-                   h->i_begin / WAVE, (h->i_end + WAVE - 1) / WAVE, sched ? h->cost : nullptr, -1,
+                   h->i_begin / WAVE, (h->i_end + WAVE - 1) / WAVE,
                    (list && a.tile_box_out) ? 1 : 0};      // (shards: run_ticks sets it, it knows whether the tick integrates)
 }
 
@@ -1155,7 +1126,7 @@ static int run_fused(SfmHandle* h, int ticks, uint32_t flags, bool carry, bool g
     h->carry_ok = true;
     h->carry_seq = h->api_seq;
     h->carry_sl = sl;
-    h->last_list = h->last_sched = h->last_split = false;
+    h->last_list = h->last_split = false;
     h->boxes_valid = false;
     h->count_zeroed = false;
     h->timed_ticks = ticks;
@@ -1199,7 +1170,7 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags, int phase = PHASE_
         TickArgs probe;
         fill_args(h, probe, flags);
         order_pays = probe.geo != nullptr || probe.tile_box != nullptr;
-        list_cut = probe.tile_box != nullptr && !probe.lite;
+        list_cut = probe.tile_box != nullptr;
         plain = probe.geo == nullptr && probe.tile_box == nullptr && probe.adv.M == 0;
         fused_geo = probe.geo != nullptr && probe.tile_box == nullptr && h->fused_geo_mode != 0;     // (SFM_FUSED=0 switches both off)
     }
@@ -1291,7 +1262,6 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags, int phase = PHASE_
             HIP_TRY(h, launch_modes(a, h->stream));
             ++launches;
         }
-        const bool lite = a.lite != 0;
         const bool carried = a.tile_box_out != nullptr && h->boxes_valid;   // the previous epilogue left this tick's boxes
         // boxes / speeds of this tick's input state (all tiles); with the two-level list the strips' boxes come out of the same launch
         const bool merged_bounds = a.tile_box && !carried && sym && list_cut && n_strips > 0 && !h->z3;
@@ -1323,13 +1293,13 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags, int phase = PHASE_
         // geometry workgroups first in the grid with as many waves per tile as the geometry kernel would use: all forces at
         // N = 512 / 2048 / 4096: 38.9 / 37.9 / 43.6 us with the geometry kernel on the side stream (round 1's default), 19.3 / 22.2 /
         // 31.0 us with it in line on the main stream, 13.9 / 16.3 / 23.2 us in the pair kernel's launch (tools/mid_crowd_probe.py).
-        const bool plain_grid = !a.tile_box && !lite;                  // no cutoff of any kind: the pair kernel runs its 2-D grid
+        const bool plain_grid = !a.tile_box;                           // no cutoff: the pair kernel runs its 2-D grid
         const bool geo_in_pair = !ahead && a.geo && n_local > 0 && sym && !finishing && a.en_ped && h->N > 1 && h->debug_steps < 0 &&
                                  !h->stamps && !h->geo_stamps && h->pair_geo_mode != 0 && (list_cut || plain_grid);
         // the geometry kernel on the side stream: shards (beside the exchange and the list), and large whole crowds whose boxes are
         // not carried; a mid-sized whole crowd keeps it in line -- two streams cost it a factor of two (numbers above)
         const bool fork = !geo_in_pair && a.geo && n_local > 0 && sym &&
-                          ((h->overlap_geo && (!whole || (fork_carried && !lite))) || finishing);
+                          ((h->overlap_geo && (!whole || fork_carried)) || finishing);
         bool list_in_geo = false;
         if (geo_in_pair) a.geo_slices = merged_geo_slices((h->i_end + WAVE - 1) / WAVE - h->i_begin / WAVE, a.geo_slices);
         if (finishing && h->begin_geo_slices > 0) a.geo_slices = h->begin_geo_slices;      // sfm_tick_begin's pair launch held the geometry workgroups
@@ -1353,22 +1323,15 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags, int phase = PHASE_
         }
         if (sym) {
             const SymArgs sa = make_sym_args(h, a, tps, n_strips, h->debug_steps, h->stamps);
-            h->last_list = sa.work != nullptr && !sa.cost;
-            h->last_sched = sa.cost != nullptr;
-            if (sa.cost && !h->sched_valid) {     // no costs yet (new crowd / new packing): deal the items in their natural order
-                HIP_TRY(h, hipMemsetAsync(h->cost, 0, sizeof(int) * (size_t)h->n_t * (size_t)(h->n_t / 2 + 1), h->stream));
-                HIP_TRY(h, launch_schedule(h->cost, h->n_t, h->work, h->work_count, h->stream));
-                h->sched_valid = true;
-                ++launches;
-            }
-            if (sa.work && !sa.cost && n_strips > 0 && !merged_bounds) {
+            h->last_list = sa.work != nullptr;
+            if (sa.work && n_strips > 0 && !merged_bounds) {
                 HIP_TRY(h, launch_strip_bounds(a.tile_box, a.tile_vmax, h->n_t, tps, n_strips, h->strip_box, h->strip_vmax, h->stream));
                 ++launches;
             }
             // a shard's epilogue leaves the list counter(s) at zero as well (its boxes cannot be carried -- the other ranks' rows
             // arrive in between -- but the memset can go)
-            const bool shard_zero = !whole && list_cut && !sa.cost && (flags & SFM_TICK_INTEGRATE) && h->carry_mode != 0;
-            if (sa.work && !sa.cost && !list_in_geo) {
+            const bool shard_zero = !whole && list_cut && (flags & SFM_TICK_INTEGRATE) && h->carry_mode != 0;
+            if (sa.work && !list_in_geo) {
                 HIP_TRY(h, launch_sym_list(a, sa, h->stream, finishing ? LIST_REMOTE : LIST_ALL, (carried || !whole) && h->count_zeroed));
                 ++launches;
             }
@@ -1398,11 +1361,11 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags, int phase = PHASE_
             h->geo_ahead = true;
             ++launches;
         }
-        // lite cutoff: the epilogue left the next tick's boxes in the other buffer (valid only if this tick moved the crowd)
+        // the epilogue left the next tick's boxes in the other buffer (valid only if this tick moved the crowd)
         if (a.tile_box_out && sym) {
             h->box_cur ^= 1;
             h->boxes_valid = (flags & SFM_TICK_INTEGRATE) != 0;
-            h->count_zeroed = !lite;
+            h->count_zeroed = true;
         } else {
             h->boxes_valid = false;
             h->count_zeroed = shard_zeroed;
@@ -1491,7 +1454,7 @@ int sfm_profile_dominant_kernel(SfmHandle* h, int reps, float* avg_us) {
     if (h->used_sym) a.geo = nullptr;
     const SymArgs sa = make_sym_args(h, a, tps, n_strips, -1, nullptr);
     if (a.tile_box) HIP_TRY(h, launch_tile_bounds(a.pk_cur, h->z3 ? a.zv_cur : nullptr, h->N, const_cast<float4*>(a.tile_box), const_cast<float*>(a.tile_vmax), h->stream));
-    if (sa.work && !sa.cost && n_strips > 0)
+    if (sa.work && n_strips > 0)
         HIP_TRY(h, launch_strip_bounds(a.tile_box, a.tile_vmax, h->n_t, tps, n_strips, h->strip_box, h->strip_vmax, h->stream));
     if (h->used_sym) HIP_TRY(h, launch_sym_list(a, sa, h->stream));      // the list is built once, outside the timed launches
     HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
@@ -1757,16 +1720,6 @@ int sfm_get_pair_work(SfmHandle* h, long long* tile_pair_items, long long* pair_
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     const long long t_own = (h->i_end + WAVE - 1) / WAVE - h->i_begin / WAVE;
     long long items, diag_items = (t_own + 1) / 2;
-    if (h->last_sched) {                           // per-item step counts of the last tick: 64 pairs per executed step
-        const size_t n_slots = (size_t)h->n_t * (size_t)(h->n_t / 2 + 1);
-        std::vector<int> c(n_slots);
-        HIP_TRY(h, hipMemcpy(c.data(), h->cost, sizeof(int) * n_slots, hipMemcpyDeviceToHost));
-        long long steps = 0, live = 0;
-        for (size_t id = (size_t)h->n_t; id < n_slots; ++id) { steps += c[id]; live += c[id] > 0; }
-        if (tile_pair_items) *tile_pair_items = live + diag_items;
-        if (pair_terms) *pair_terms = steps * (long long)WAVE + t_own * (long long)(WAVE * WAVE / 2);
-        return SFM_OK;
-    }
     if (h->last_list) {
         int cnt[4] = {0, 0, 0, 0};
         HIP_TRY(h, hipMemcpy(cnt, h->work_count, sizeof(int) * 4, hipMemcpyDeviceToHost));

@@ -104,9 +104,8 @@ struct TickArgs {
     const float* tile_vmax;   // [n_t] largest speed in the tile
     float cut_scale;          // gamma * 41 ln 2 (with margin): distance per unit of (lambda*(va+vb)+1)
     float cut_pad;            // 2 * largest radius when use_ped_radius, else 0
-    float4* tile_box_out;     // lite cutoff, and the list cutoff of a whole crowd: the symmetric epilogue writes the boxes / speeds of
+    float4* tile_box_out;     // the list cutoff of a whole crowd: the symmetric epilogue writes the boxes / speeds of
     float* tile_vmax_out;     // the NEXT tick's state here (saves the next tick's sfm_tile_bounds_kernel launch)
-    int lite;                 // 1: the "lite" cutoff (no tile-pair list) is what tile_box stands for
     FsmArgs fsm;
     // Flat tile-pair list of a whole crowd built by extra workgroups of the geometry launch (block index >= list_block0) instead of
     // a launch of its own: the boxes were left by the previous epilogue, so nothing stands in front of it.  list_work == null: off.
@@ -122,14 +121,11 @@ struct SymArgs {
     float* slabz;        // 3-D crowds: its z component, same indexing (null: planar)
     int n_t;             // number of 64-pedestrian tiles
     int stride;          // n_t * 64
-    int dir;             // lane direction of the DPP wavefront rotate (+1: lane l receives lane l+1), calibrated at init
     int debug_steps;     // < 0: normal; >= 0: run only this many systolic steps per wave (timing probe, wrong results)
     const uint32_t* work;    // cutoff on: compacted list of (bx | shift << 16) tile-pair items, else null
     const int* work_count;
-    // "lite" cutoff for small crowds (no list): each workgroup tests its own tile pair and leaves if negligible (box != null);
-    // vmax (largest speed per tile, this tick's input state) is set whenever a cutoff is on, list or lite: the pair kernel
-    // then also skips the systolic steps whose 64 pairs are all beyond the reach of the two tiles' speeds
-    const float4* box;
+    // vmax (largest speed per tile, this tick's input state) is set whenever the list cutoff is on: the pair kernel then also
+    // skips the systolic steps whose 64 pairs are all beyond the reach of the two tiles' speeds, or below the exponent bound
     const float* vmax;
     float cut_scale, cut_pad;
     unsigned long long* stamps;   // diagnostic builds of a run only (SFM_STAMPS): per workgroup {start, end} of s_memrealtime + HW id
@@ -140,11 +136,6 @@ struct SymArgs {
     int tps, n_strips;
     int t_lo, t_hi;      // tiles of this handle's rows (a shard; whole crowd: 0, n_t).  Pairs with a tile outside are
                          // evaluated one-sided: the other side belongs to another rank, which evaluates it itself
-    // Scheduled lite cutoff (mid-sized whole crowds): `work` holds ALL tile-pair items in the order sfm_schedule_items dealt
-    // them (one item per workgroup) and every workgroup leaves the number of systolic steps it executed, 0..64, in
-    // cost[shift * n_t + bx] -- the next tick's order is dealt from those.  cost == null: off.
-    int* cost;
-    int sched_block;     // epilogue launch: index of the extra workgroup that deals the next tick's order (-1: none)
     int zero_count;      // epilogue launch: 1 = leave *work_count at 0 for the next tick's list kernel (saves its memset)
 };
 

@@ -1379,12 +1379,8 @@ __global__ __launch_bounds__(LIST2_WAVES * WAVE) void sfm_pair_list2_kernel(cons
 // exactly 0, so no masking is needed.  Planar crowds without use_ped_radius only (whole crowd, or a shard of whole
 // tiles under the tile-pair list, where a pair with another rank's tile is evaluated one-sided); anything else uses
 // the ordered kernel above.
-__device__ __forceinline__ float rot1(float v) {
-    const int b = __float_as_int(v);   // old == src: lets the register allocator rotate in place (no pre-clear move)
-    return __int_as_float(__builtin_amdgcn_update_dpp(b, b, 0x134 /* wave_rol:1 */, 0xf, 0xf, false));
-}
-
-// the same move with nothing kept of the old value: foldable into the VALU instruction that consumes it (v_add_f32_dpp)
+// wave_rol:1 of a value: lane l receives lane l + 1's (probed at init).  With nothing kept of the old value the move folds into the
+// VALU instruction that consumes it (v_add_f32_dpp)
 __device__ __forceinline__ float rot_in(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x134 /* wave_rol:1 */, 0xf, 0xf, true));
 }
@@ -1397,7 +1393,6 @@ __global__ void sfm_dpp_probe_kernel(int* out) {       // which way does wave_ro
 struct PairShared {                             // LDS of one pair workgroup
     float2 fi[WAVES_PER_BLOCK][WAVE];
     float2 fj[WAVES_PER_BLOCK][WAVE];
-    int cnt[WAVES_PER_BLOCK];
     float4 trav[2][2 * WAVE];                   // the travelling tile(s) {x, y, lambda vx, lambda vy}, each twice back to back (two: a diagonal item)
     float radt[2][2 * WAVE];                    // ... and their radii (use_ped_radius)
     float2 travz[2][2 * WAVE];                  // 3-D crowds: {z, lambda vz} of the travelling tile(s)
@@ -1456,8 +1451,6 @@ __device__ __forceinline__ void pair_block(const float4* __restrict__ pk, const 
     float fxi = 0.f, fyi = 0.f, fxj = 0.f, fyj = 0.f;
     float fzi = 0.f, fzj = 0.f;                   // 3-D crowds (Z3): the z components (forces.py:112-117 keeps 3-component forces)
     int i_end_loc = lane;
-    int executed = 0;                             // systolic steps this wave evaluated (uniform)
-    bool negligible = false;                      // lite cutoff: the whole tile pair is provably below 2^-40 A
     // The travelling tile goes through LDS (round 3): one wave stages it, twice back to back and with lambda v folded in, and
     // step s of a lane is one ds_read_b128 at slot lane + sig0 + s -- no operand moves between lanes on the VALU; only the two
     // travelling sums still rotate, inside the add that takes the step's term (v_add_f32_dpp).  54 instead of 60 VALU per step.
@@ -1478,13 +1471,10 @@ __device__ __forceinline__ void pair_block(const float4* __restrict__ pk, const 
         if (Z3) { const float2 qz = zv[tb * WAVE + lane]; zj = qz.x; ujz = c.lam * qz.y; }
         float reach2 = __builtin_inff();             // CUT: squared distance beyond which a term is < 2^-40 A (uniform)
         if (CUT && shift != 0) {
-            // lite cutoff: every term of this tile pair is provably < 2^-40 A -> nothing to do; the epilogue applies the same
-            // test and does not read this pair's slab rows
-            negligible = sa.box && tiles_negligible(sa.box[ta], sa.vmax[ta], sa.box[tb], sa.vmax[tb], c.lam, sa.cut_scale, sa.cut_pad);
             const float reach = fmaf(sa.cut_scale, fmaf(c.lam, sa.vmax[ta] + sa.vmax[tb], 1.0f), sa.cut_pad);
             reach2 = reach * reach;
         }
-      if (!negligible) {
+      {
         // lambda v travels with i / stays with j: D = lambda (v_i - v_j) + e is then one fma per component
         const float ujx = c.lam * pj.z, ujy = c.lam * pj.w;
         const float4* trav = &sh.trav[tsel][lane + sig0];
@@ -1519,7 +1509,6 @@ __device__ __forceinline__ void pair_block(const float4* __restrict__ pk, const 
                     fyi = rot_in(fyi) + cy;
                     if (Z3) fzi = rot_in(fzi) + cz;
                     if (s_ < one_sided_from) { fxj -= cx; fyj -= cy; if (Z3) fzj -= cz; }
-                    ++executed;
                     done = true;
                 }
             }
@@ -1542,12 +1531,8 @@ __device__ __forceinline__ void pair_block(const float4* __restrict__ pk, const 
     sh.fi[wave][i_end_loc] = make_float2(fxi, fyi);
     sh.fj[wave][lane] = make_float2(fxj, fyj);
     if (Z3) { sh.fiz[wave][i_end_loc] = fzi; sh.fjz[wave][lane] = fzj; }
-    if (sa.cost && lane == 0) sh.cnt[wave] = executed;
     __syncthreads();
-    if (sa.cost && tid == 0) sa.cost[shift * n_t + bx] = (sh.cnt[0] + sh.cnt[1]) + (sh.cnt[2] + sh.cnt[3]);
-    if (negligible) {
-        // nothing written: the epilogue applies the same (bitwise symmetric) test and does not read this pair's slab rows
-    } else if (shift == 0) {
+    if (shift == 0) {
         // waves 0,1 -> tile bx ; waves 2,3 -> tile bx + half_up
         if (tid < 2 * WAVE) {
             const int g = tid >> 6;                       // 0 or 1
@@ -1623,71 +1608,6 @@ __global__ __launch_bounds__(BLOCK) void sfm_pair_geo_kernel(const TickArgs a, c
     }
 }
 
-// Deals the tile-pair items of the NEXT tick to the workgroups of the pair kernel (scheduled lite cutoff, whole crowd).
-// Under the per-step reach test a tile pair costs anything between nothing and 64 steps, all workgroups of a mid-sized crowd
-// are resident at once, and a CU's time is the sum of its eight: a corner tile's partners are mostly out of reach, a central
-// tile's are not.  The dispatcher places workgroup w on CU (w mod 256) -- round-robin over the 8 XCDs, then over an XCD's
-// CUs, observed on MI355X (tools/cu_map_probe.py); nothing but speed depends on it -- so the items are sorted by the
-// cost they had in the tick before (counting sort, 65 buckets) and dealt in rounds of 256, every other round backwards:
-// each CU gets one item of every cost octile.  One workgroup of `nthreads` threads.
-constexpr int SCHED_CUS = 256;
-__device__ void sfm_schedule_items(const int* __restrict__ cost, int n_t, uint32_t* __restrict__ work, int* __restrict__ count,
-                                   int tid, int nthreads, int* s_hist /* [66] */) {
-    const int n_slots = n_t * (n_t / 2 + 1);
-    const int half_up = (n_t + 1) >> 1;
-    auto active = [&](int id) {
-        const int shift = id / n_t, bx = id - shift * n_t;
-        if (shift == 0) return bx < half_up;
-        return !(!(n_t & 1) && shift == (n_t >> 1) && bx >= (n_t >> 1));
-    };
-    for (int q = tid; q < 66; q += nthreads) s_hist[q] = 0;
-    __syncthreads();
-    for (int id = tid; id < n_slots; id += nthreads)
-        if (active(id)) atomicAdd(&s_hist[64 - min(max(cost[id], 0), 64)], 1);      // bucket 0 = the most expensive
-    __syncthreads();
-    if (tid < WAVE) {                                                                // exclusive prefix over the 65 buckets: one wave
-        const int v = s_hist[tid];
-        int incl = v;
-#pragma unroll
-        for (int d = 1; d < WAVE; d <<= 1) {
-            const int o = __shfl_up(incl, d);
-            if (tid >= d) incl += o;
-        }
-        const int last = s_hist[64];
-        s_hist[tid] = incl - v;
-        if (tid == WAVE - 1) {
-            s_hist[64] = incl;                                                       // the cost-0 bucket comes after all others
-            s_hist[65] = incl + last;                                                // number of items
-            *count = incl + last;
-        }
-    }
-    __syncthreads();
-    const int m = s_hist[65];
-    // position inside a bucket: first come, first served (an LDS atomic per item).  Which workgroup evaluates an item has no
-    // influence on any result -- every slab row is written exactly once whoever writes it -- so the arbitrary order inside a
-    // bucket only moves equal-cost items between CUs.
-    for (int id = tid; id < n_slots; id += nthreads) {
-        if (!active(id)) continue;
-        const int b = 64 - min(max(cost[id], 0), 64);
-        const int p = atomicAdd(&s_hist[b], 1);                                      // rank in the cost-descending order
-        const int round = p / SCHED_CUS, pos = p - round * SCHED_CUS;
-        const int width = min(SCHED_CUS, m - round * SCHED_CUS);
-        const int slot = round * SCHED_CUS + ((round & 1) ? (width - 1 - pos) : pos);
-        const int shift = id / n_t, bx = id - shift * n_t;
-        work[slot] = (uint32_t)bx | ((uint32_t)shift << 16);
-    }
-}
-
-__global__ __launch_bounds__(1024) void sfm_schedule_kernel(const int* __restrict__ cost, int n_t, uint32_t* __restrict__ work,
-                                                            int* __restrict__ count) {
-    __shared__ int s_hist[66];
-    sfm_schedule_items(cost, n_t, work, count, threadIdx.x, blockDim.x, s_hist);
-}
-
-// Epilogue of the symmetric path: one workgroup of 16 waves per tile of 64 pedestrians.  The waves split the
-// partner tiles of the slab column sum (all loads of a wave in flight at once, combined in LDS in a fixed
-// order) and wave 0 integrates the 64 pedestrians lane-parallel with coalesced loads and stores (geometry
-// forces come from sfm_geometry_kernel).  Latency-bound by design: few, short chains.
 constexpr int EPI_WAVES = 16;
 #ifndef EPI_INFLIGHT
 #define EPI_INFLIGHT 8                     // slab-row loads a wave keeps in flight under a cutoff (a multiple of 4; the sum's association follows it)
@@ -1705,11 +1625,6 @@ __global__ __launch_bounds__(EW * WAVE) void sfm_sym_epilogue_kernel(const TickA
     const int tid = threadIdx.x;
     const int lane = tid & (WAVE - 1);
     const int wave = uniform(tid >> 6);
-    if (sa.sched_block >= 0 && (int)blockIdx.x == sa.sched_block) {  // one more extra workgroup: the next tick's item order
-        __shared__ int s_hist[66];
-        sfm_schedule_items(sa.cost, sa.n_t, const_cast<uint32_t*>(sa.work), const_cast<int*>(sa.work_count), tid, (EW * WAVE), s_hist);
-        return;
-    }
     if (a.adv.M > 0 && (int)blockIdx.x >= a.adv.block0) {            // the extra workgroups: vehicles move on
         const int k = ((int)blockIdx.x - a.adv.block0) * EW + wave;
         if (k < a.adv.M) advance_vehicle(a.adv, k, lane, true);
@@ -1978,7 +1893,7 @@ __global__ __launch_bounds__(EW * WAVE) void sfm_sym_epilogue_kernel(const TickA
     if (despawn || gone) { const float2 pp = park_position(pid); nx = pp.x; ny = pp.y; nvx = 0.f; nvy = 0.f; nvz = 0.f; }
     if (live) a.pk_next[i] = make_float4(nx, ny, nvx, nvy);
     if (Z3 && live) a.zv_next[i] = make_float2(nz, nvz);
-    if (a.tile_box_out) {                             // lite cutoff: box and largest speed of the tile in the NEXT state
+    if (a.tile_box_out) {                             // whole crowd under the list cutoff: box and largest speed of the tile in the NEXT state
         const float inf = __builtin_inff();
         const bool in_box = live && fabsf(nx) < 1.0e14f;
         float x0 = in_box ? nx : inf, y0 = in_box ? ny : inf, x1 = in_box ? nx : -inf, y1 = in_box ? ny : -inf;
@@ -2056,7 +1971,7 @@ struct FusedShared {                             // LDS of one pair-role workgro
 };
 
 template <bool RAD, int NW, bool Z3, bool GEO>   // NW waves per workgroup (8 or 16): 256 / NW systolic steps each
-__global__ __launch_bounds__(NW * WAVE, 8) void sfm_fused_tick_kernel(const TickArgs a, const FusedArgs f) {   // 8 waves per SIMD: two 16-wave (four 8-wave) workgroups per CU
+__global__ __launch_bounds__(NW * WAVE, (NW == 8 && Z3) ? 6 : 8) void sfm_fused_tick_kernel(const TickArgs a, const FusedArgs f) {   // 8 waves per SIMD: two 16-wave (four 8-wave) workgroups per CU (3-D, 8 waves: LDS allows three)
     constexpr int PARTS = NW / 2;                // the slab rows are split over this many 128-thread parts
     constexpr int SPW = 4 * WAVE / NW;           // systolic steps per wave
     constexpr int D = NW / 8;                    // waves per diagonal tile
@@ -2540,7 +2455,7 @@ hipError_t launch_geometry(bool rad, const TickArgs& a, hipStream_t st) {
 
 // cutoff on: compact the tile pairs that have to be evaluated (the work list of the pair kernel)
 hipError_t launch_sym_list(const TickArgs& a, const SymArgs& sa, hipStream_t st, int partners = PARTNERS_ALL, bool count_is_zero = false) {
-    if (a.N <= 1 || !a.en_ped || !sa.work || sa.cost) return hipSuccess;       // (scheduled mode: the order is dealt, not built)
+    if (a.N <= 1 || !a.en_ped || !sa.work) return hipSuccess;
     hipError_t e = count_is_zero ? hipSuccess : hipMemsetAsync(const_cast<int*>(sa.work_count), 0, sizeof(int), st);
     if (e != hipSuccess) return e;
     const bool whole = sa.t_lo == 0 && sa.t_hi == sa.n_t;      // a shard also looks at partners behind it
@@ -2555,8 +2470,6 @@ hipError_t launch_sym_list(const TickArgs& a, const SymArgs& sa, hipStream_t st,
                            const_cast<uint32_t*>(sa.work), const_cast<int*>(sa.work_count), partners);
     return hipGetLastError();
 }
-
-int sym_item_count(int n_t);
 
 template <bool RAD, bool CUT>
 static void launch_sym_pair_t(dim3 grid, const TickArgs& a, const SymArgs& sa, hipStream_t st) {
@@ -2580,9 +2493,9 @@ hipError_t launch_sym_pair(bool rad, const TickArgs& a, const SymArgs& sa, hipSt
         // 1024 tiles on
         static const int rounds_ov = exp_env("SFM_ROUNDS") ? atoi(exp_env("SFM_ROUNDS")) : 0;      // A/B only
         const int rounds = rounds_ov > 0 ? rounds_ov : std::min(16, std::max(2, sa.n_t / 64));
-        grid = sa.cost ? dim3(sym_item_count(sa.n_t)) : dim3(256 * 8 * rounds);    // scheduled: one dealt item per workgroup
+        grid = dim3(256 * 8 * rounds);
     }
-    const bool cut = sa.vmax != nullptr;           // list or lite cutoff: the per-step reach test is on as well
+    const bool cut = sa.vmax != nullptr;           // list cutoff: the per-step reach and exponent tests are on as well
     if (rad) { if (cut) launch_sym_pair_t<true, true>(grid, a, sa, st); else launch_sym_pair_t<true, false>(grid, a, sa, st); }
     else { if (cut) launch_sym_pair_t<false, true>(grid, a, sa, st); else launch_sym_pair_t<false, false>(grid, a, sa, st); }
     return hipGetLastError();
@@ -2599,7 +2512,7 @@ hipError_t launch_sym_pair_geo(bool rad, const TickArgs& a, const SymArgs& sa, h
     int stride = n_geo > 256 * 4 ? std::max(1, (n_geo + n_pair) / n_geo) : 1;
     if (stride_ov > 0) stride = std::min(stride_ov, std::max(1, (n_geo + n_pair) / n_geo));
     if (stride > 1 && !(stride & 1)) --stride;      // odd: workgroup w runs on CU w mod 256, an even stride would put every geometry workgroup on a few CUs
-    const bool cut = sa.vmax != nullptr;           // as launch_sym_pair: list (or lite) cutoff -> the per-step tests are on
+    const bool cut = sa.vmax != nullptr;           // as launch_sym_pair: list cutoff -> the per-step tests are on
     if (rad) { if (cut) launch_sym_pair_geo_t<true, true>(grid, a, sa, tiles, stride, st); else launch_sym_pair_geo_t<true, false>(grid, a, sa, tiles, stride, st); }
     else { if (cut) launch_sym_pair_geo_t<false, true>(grid, a, sa, tiles, stride, st); else launch_sym_pair_geo_t<false, false>(grid, a, sa, tiles, stride, st); }
     return hipGetLastError();
@@ -2634,20 +2547,17 @@ static void launch_sym_epilogue_t(const TickArgs& a, const SymArgs& sa, hipStrea
     SymArgs sb = sa;
     b.adv.block0 = sa.t_hi - sa.t_lo;
     const int extra = a.adv.M > 0 ? (a.adv.M + EW - 1) / EW : 0;
-    const int sched = (sa.cost && EW == EPI_WAVES) ? 1 : 0;   // scheduled lite cutoff: one more workgroup deals the next tick's order
-    sb.sched_block = sched ? sa.t_hi - sa.t_lo + extra : -1;
-    const dim3 grid(sa.t_hi - sa.t_lo + extra + sched);
+    const dim3 grid(sa.t_hi - sa.t_lo + extra);
     if (sa.slabz) hipLaunchKernelGGL((sfm_sym_epilogue_kernel<RAD, EW, true>), grid, dim3(EW * WAVE), 0, st, b, sb);
     else hipLaunchKernelGGL((sfm_sym_epilogue_kernel<RAD, EW, false>), grid, dim3(EW * WAVE), 0, st, b, sb);
 }
 
 // 16 waves per tile for small and mid-sized crowds (one dependent round of slab-row loads); from 1024 tiles on there are
-// plenty of workgroups and 4 waves per tile measured 2 % better on the c5 tick (the dealer of the scheduled lite cutoff, a
-// mid-sized-crowd feature, needs the 16-wave form).
+// plenty of workgroups and 4 waves per tile measured 2 % better on the c5 tick.
 hipError_t launch_sym_epilogue(bool rad, const TickArgs& a, const SymArgs& sa, hipStream_t st) {
     if (a.N <= 0) return hipSuccess;
     static const int ew_ov = exp_env("SFM_EPI_WAVES") ? atoi(exp_env("SFM_EPI_WAVES")) : 0;      // A/B only: 4 / 16
-    const bool thin = (ew_ov ? ew_ov == 4 : sa.n_t >= 1024) && !sa.cost;
+    const bool thin = ew_ov ? ew_ov == 4 : sa.n_t >= 1024;
     if (rad) { if (thin) launch_sym_epilogue_t<true, 4>(a, sa, st); else launch_sym_epilogue_t<true, EPI_WAVES>(a, sa, st); }
     else { if (thin) launch_sym_epilogue_t<false, 4>(a, sa, st); else launch_sym_epilogue_t<false, EPI_WAVES>(a, sa, st); }
     return hipGetLastError();
@@ -2675,15 +2585,6 @@ hipError_t launch_fused_tick(bool rad, const TickArgs& a, const FusedArgs& f, hi
     const dim3 grid(f.n_geo_wg + f.n_pair_wg + n_adv);
     if (nw == 8) { if (rad) launch_fused_t<true, 8>(grid, geo, z3, a, f, st); else launch_fused_t<false, 8>(grid, geo, z3, a, f, st); }
     else { if (rad) launch_fused_t<true, 16>(grid, geo, z3, a, f, st); else launch_fused_t<false, 16>(grid, geo, z3, a, f, st); }
-    return hipGetLastError();
-}
-
-// number of tile-pair items of a whole crowd of n_t tiles (what sfm_schedule_items deals): every unordered tile pair once +
-// the diagonal items (two diagonal tiles each)
-int sym_item_count(int n_t) { return n_t * (n_t - 1) / 2 + (n_t + 1) / 2; }
-
-hipError_t launch_schedule(const int* cost, int n_t, uint32_t* work, int* count, hipStream_t st) {
-    hipLaunchKernelGGL(sfm_schedule_kernel, dim3(1), dim3(1024), 0, st, cost, n_t, work, count);
     return hipGetLastError();
 }
 

@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of the c2 tick under different SFM_* settings:  bash tools/ab_c2.sh "SFM_CUTOFF=0" "SFM_CUTOFF=2" ...
+# A/B of the c2 tick under different SFM_* settings:  bash tools/ab_c2.sh "SFM_FUSED=0" "SFM_FUSED=1" ...
 cd $GRAFT_REPO_ROOT
 for env in "$@"; do
   echo "== $env"
