@@ -1,6 +1,6 @@
 #!/bin/bash
 # one gpurun call: GPU tests, c2 bench line, kernel-trace stats of the same command, PMC passes.   bash tools/gpu_round.sh <tag> [workloads...]
-tag=${1:-r02}; shift
+tag=${1:-r03}; shift
 wl=${@:-c2}
 root=$GRAFT_REPO_ROOT
 out=$root/gpurun_out

@@ -14,7 +14,7 @@ export SFM_PAIR_GEO=0
 specs=""
 for w in $wl; do
   t=40; [ $w = c5 ] && t=12
-  export PMC_META=$out/$w/meta.json
+  mkdir -p $out/$w; export PMC_META=$out/$w/meta.json
   rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAVES SQ_INSTS_SALU GRBM_GUI_ACTIVE \
       --output-format csv -d $out/$w/sq -o p -- python3 $root/tools/pmc_ticks.py $w $t > $out/${w}_sq.log 2>&1 || exit 1
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/$w/fetch -o p -- python3 $root/tools/pmc_ticks.py $w $t > $out/${w}_fetch.log 2>&1 || exit 1

@@ -24,6 +24,7 @@ if meta:
         items, terms = eng.engine.pair_work()
     except Exception:
         items, terms = 0, 0
+    os.makedirs(os.path.dirname(meta), exist_ok=True)
     with open(meta, "w") as f:
         json.dump({"workload": name, "ticks": ticks, "kernel_variant": eng.engine.kernel_variant(), "pair_items": items, "pair_terms": terms}, f)
 eng.close()
