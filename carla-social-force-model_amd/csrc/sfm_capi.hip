@@ -160,6 +160,7 @@ struct SfmHandle {
     float4* dyn_ctr_alt = nullptr;         // device-side vehicles in the fused tick: the NEXT tick's centres / rings (ping-pong with dynamics.ctr / .pts)
     float2* dyn_pts_alt = nullptr;
     size_t dyn_ctr_alt_cap = 0, dyn_pts_alt_cap = 0;
+    unsigned long long* fused_stamps = nullptr;   // experiments build, SFM_FUSED_STAMPS=<file>: phase stamps of the last fused launch
     int fused_geo_slices = 0;              // SFM_FUSED_GEO_SLICES: A/B
     int fused_geo_mode = -1;               // SFM_FUSED_GEO=0: crowds with border / obstacle forces keep the two-launch tick (A/B, tests)
     bool used_fused = false;
@@ -369,6 +370,10 @@ int sfm_create(const SfmParams* params, int device_id, SfmHandle** out) {
             if (f) fclose(f);
         }
     }
+    if (exp_env("SFM_FUSED_STAMPS")) {
+        if (hipMalloc(reinterpret_cast<void**>(&h->fused_stamps), sizeof(unsigned long long) * 5 * 4096) != hipSuccess) h->fused_stamps = nullptr;
+        else hipMemset(h->fused_stamps, 0, sizeof(unsigned long long) * 5 * 4096);
+    }
     if (exp_env("SFM_GEO_STAMPS")) {
         if (hipMalloc(reinterpret_cast<void**>(&h->geo_stamps), sizeof(unsigned long long) * 4 * 8192) != hipSuccess) h->geo_stamps = nullptr;
         else hipMemset(h->geo_stamps, 0, sizeof(unsigned long long) * 4 * 8192);
@@ -398,6 +403,14 @@ int sfm_destroy(SfmHandle* h) {
             if (f) { for (size_t b = 0; b < 8192; ++b) fprintf(f, "%llu %llu %llu\n", st[3 * b], st[3 * b + 1], st[3 * b + 2]); fclose(f); }
         }
         hipFree(h->stamps);
+    }
+    if (h->fused_stamps && exp_env("SFM_FUSED_STAMPS")) {   // diagnostic: the last fused launch's per-workgroup phase stamps
+        std::vector<unsigned long long> st((size_t)5 * 4096);
+        if (hipMemcpy(st.data(), h->fused_stamps, sizeof(unsigned long long) * st.size(), hipMemcpyDeviceToHost) == hipSuccess) {
+            FILE* f = fopen(exp_env("SFM_FUSED_STAMPS"), "w");
+            if (f) { for (size_t b = 0; b < 4096; ++b) if (st[5 * b]) fprintf(f, "%zu %llu %llu %llu %llu %llu\n", b, st[5 * b], st[5 * b + 1], st[5 * b + 2], st[5 * b + 3], st[5 * b + 4]); fclose(f); }
+        }
+        hipFree(h->fused_stamps);
     }
     if (h->geo_stamps && exp_env("SFM_GEO_STAMPS")) {   // diagnostic: dump the last launch's per-workgroup phase stamps
         std::vector<unsigned long long> st(4 * 8192);
@@ -1068,7 +1081,7 @@ static int fused_launch(SfmHandle* h, uint32_t flags, int mode, int* sl) {
                       h->z3 ? h->fslabz + (size_t)(*sl ^ 1) * rows : nullptr, h->z3 ? h->fslabz + (size_t)*sl * rows : nullptr,
                       h->own, h->own_alt, n_g, h->n_t, (h->fused_blocked != 0 && n_g % 8 == 0) ? 1 : 0,
                       geo ? h->fgeo + (size_t)(*sl ^ 1) * grow : nullptr, geo ? h->fgeo + (size_t)*sl * grow : nullptr, slices,
-                      geo ? h->n_t * slices : 0, n_pair, mode};
+                      geo ? h->n_t * slices : 0, n_pair, h->fused_stamps, mode};
     HIP_TRY(h, launch_fused_tick(h->rad, a, f, h->stream, nw));
     if (mode != 0) {
         h->cur ^= 1;

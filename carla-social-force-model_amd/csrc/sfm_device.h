@@ -159,6 +159,7 @@ struct FusedArgs {
     int geo_slices;           // <= 4
     int n_geo_wg;             // geometry workgroups in front of the grid = n_t * geo_slices (0: the crowd has no such forces)
     int n_pair_wg;            // pair workgroups behind them
+    unsigned long long* stamps;   // experiments build only (SFM_FUSED_STAMPS): per workgroup 5 x s_memrealtime -- entry, column sums in, state in LDS, pairs done, end
     int mode;                 // 0: the stored state is the state (nothing to integrate, nothing stored but slab_next): the launch in
                               //    front of a run; 1: integrate by one tick, store, then the pairs of the new state
 };

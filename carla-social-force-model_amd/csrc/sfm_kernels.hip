@@ -1970,6 +1970,12 @@ struct FusedShared {                             // LDS of one pair-role workgro
     float fjz[Z3 ? NW : 1][WAVE];
 };
 
+#ifdef SFM_EXPERIMENTS
+#define FUSED_STAMP(k) do { if (f.stamps && threadIdx.x == 0) f.stamps[5 * (size_t)blockIdx.x + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define FUSED_STAMP(k) do { } while (0)
+#endif
+
 template <bool RAD, int NW, bool Z3, bool GEO>   // NW waves per workgroup (8 or 16): 256 / NW systolic steps each
 __global__ __launch_bounds__(NW * WAVE, (NW == 8 && Z3) ? 6 : 8) void sfm_fused_tick_kernel(const TickArgs a, const FusedArgs f) {   // 8 waves per SIMD: two 16-wave (four 8-wave) workgroups per CU (3-D, 8 waves: LDS allows three)
     constexpr int PARTS = NW / 2;                // the slab rows are split over this many 128-thread parts
@@ -1979,6 +1985,7 @@ __global__ __launch_bounds__(NW * WAVE, (NW == 8 && Z3) ? 6 : 8) void sfm_fused_
     constexpr size_t LDS = (GEO && sizeof(GeoShared<NW>) > sizeof(Sh)) ? sizeof(GeoShared<NW>) : sizeof(Sh);
     __shared__ __attribute__((aligned(16))) char smem[LDS];
     Sh& sh = *reinterpret_cast<Sh*>(smem);
+    FUSED_STAMP(0);
     const int tid = threadIdx.x;
     const int lane = tid & (WAVE - 1);
     const int wave = uniform(tid >> 6);
@@ -2125,6 +2132,7 @@ __global__ __launch_bounds__(NW * WAVE, (NW == 8 && Z3) ? 6 : 8) void sfm_fused_
         sh.q[part][2 * pp + 1] = make_float2(acc4.z, acc4.w);
         if (Z3) { sh.qz[Z3 ? part : 0][2 * pp] = accz.x; sh.qz[Z3 ? part : 0][2 * pp + 1] = accz.y; }
     }
+    FUSED_STAMP(1);
     __syncthreads();
     // the arithmetic of sfm_sym_epilogue_kernel without border / obstacle forces (pedestrian_simulation.py:57-83,
     // forces.py:40-52): acceleration towards the waypoint, capped velocity, position, arrival -> next waypoint
@@ -2254,6 +2262,7 @@ __global__ __launch_bounds__(NW * WAVE, (NW == 8 && Z3) ? 6 : 8) void sfm_fused_
         return;
     }
 
+    FUSED_STAMP(2);
     // ---- 2. this workgroup's tile pairs on the new state: every wave SPW systolic steps (sfm_pair_sym_kernel's step)
     int ia, ib, sig0;                             // LDS slots of the travelling / resident tile's lane 0, first rotation
     bool diag = false, work = true;
@@ -2330,6 +2339,7 @@ __global__ __launch_bounds__(NW * WAVE, (NW == 8 && Z3) ? 6 : 8) void sfm_fused_
     sh.fi[wave][i_end_loc] = make_float2(fxi, fyi);
     sh.fj[wave][lane] = make_float2(fxj, fyj);
     if (Z3) { sh.fiz[Z3 ? wave : 0][i_end_loc] = fzi; sh.fjz[Z3 ? wave : 0][lane] = fzj; }
+    FUSED_STAMP(3);
     __syncthreads();
     if (!lower || !present) return;
     const int tl = (p >> 6) & 1, l = lane;       // tile of the group, pedestrian of the tile
@@ -2364,6 +2374,7 @@ __global__ __launch_bounds__(NW * WAVE, (NW == 8 && Z3) ? 6 : 8) void sfm_fused_
     }
     f.slab_next[(size_t)row * a.N_pad + i] = make_float2(r.x, r.y);
     if (Z3) f.slabz_next[(size_t)row * a.N_pad + i] = r.z;
+    FUSED_STAMP(4);
 }
 
 // Dynamic obstacles on the device (obstacles.py:297-329 without the simulator): one wave per vehicle moves the centre
