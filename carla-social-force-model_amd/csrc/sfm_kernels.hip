@@ -2332,7 +2332,9 @@ __global__ __launch_bounds__(NW * WAVE, (NW == 8 && Z3) ? 6 : 8) void sfm_fused_
             T = Tn;
             ri = rin;
             Tz = Tzn;
-            __builtin_amdgcn_sched_barrier(0);       // steps are not interleaved: eight waves per SIMD hide a step's chain
+            // steps are not interleaved (measured again in round 3, variant builds: without this barrier 16.44, without either 16.60,
+            // pairs of steps free to interleave 16.51, as here 16.15-16.30 us per c2 tick)
+            __builtin_amdgcn_sched_barrier(0);
         }
         i_end_loc = (lane + sig0 + SPW - 1) & (WAVE - 1);
     }
