@@ -1192,22 +1192,25 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags, int phase = PHASE_
     const bool whole = h->i_begin == 0 && h->i_end == h->N;
     const bool tile_shard = n_local > 0 && (h->i_begin % WAVE) == 0 && ((h->i_end % WAVE) == 0 || h->i_end == h->N) && list_cut &&
                             h->n_t < 32768;
-    const bool sym = (whole || tile_shard) && h->slab && need <= h->slab_cap && (!h->z3 || (h->slabz && need <= h->slabz_cap)) &&
-                     h->dpp_dir == 1 && h->prm.enabled[SFM_FORCE_PEDESTRIAN] &&
-                     (h->sym_mode == 1 || (h->sym_mode < 0 && h->N >= 256));
+    const bool sym_any_size = (whole || tile_shard) && h->slab && need <= h->slab_cap && (!h->z3 || (h->slabz && need <= h->slabz_cap)) &&
+                              h->dpp_dir == 1 && h->prm.enabled[SFM_FORCE_PEDESTRIAN];
+    // ---- a device-resident run of a whole crowd below the list cutoff: one launch per tick (sfm_fused_tick_kernel).
+    //      Every sfm_run / sfm_run_recorded takes it, whatever its length -- what a device-resident run computes must not depend on
+    //      how the caller cuts it into calls (a lone sfm_run(1) pays a launch in front like the two-launch tick pays its epilogue) --
+    //      and a single sfm_tick when it carries on from such a run.
+    const bool fusable = whole && (plain || fused_geo) && phase == PHASE_FULL && (device_run || carry) && h->fused_mode != 0 &&
+                         (flags & SFM_TICK_INTEGRATE) && !(flags & SFM_TICK_RECORD_FORCES) && !h->fsm_on && h->debug_steps < 0 && !h->stamps &&
+                         !h->geo_stamps && h->N >= 2;
+    // Auto mode keeps host-in-the-loop ticks of crowds under 256 pedestrians on the ordered kernel (one launch against the symmetric
+    // path's two); their device-resident runs are one launch per tick on the fused kernel like everybody else's (round 3: c1).
+    const bool small_run = h->sym_mode < 0 && h->N < 256 && fusable;
+    const bool sym = sym_any_size && (h->sym_mode == 1 || (h->sym_mode < 0 && h->N >= 256) || small_run);
     h->used_sym = sym;
     if (sym) snprintf(h->variant, sizeof(h->variant), "sfm_pair_sym_kernel+sfm_sym_epilogue_kernel");
     else snprintf(h->variant, sizeof(h->variant), "sfm_tick_kernel<%d,%s,%s,%d>", ipw, h->z3 ? "true" : "false",
                   h->rad ? "true" : "false", team);
     h->used_fused = false;
-    // ---- several ticks of a whole crowd with nothing but the acceleration and pedestrian forces: one launch per tick
-    //      Every sfm_run / sfm_run_recorded takes it, whatever its length -- what a device-resident run computes must not depend on
-    //      how the caller cuts it into calls (a lone sfm_run(1) pays a launch in front like the two-launch tick pays its epilogue) --
-    //      and a single sfm_tick when it carries on from such a run.
-    if (sym && whole && (plain || fused_geo) && phase == PHASE_FULL && (device_run || carry) && h->fused_mode != 0 &&
-        (flags & SFM_TICK_INTEGRATE) && !(flags & SFM_TICK_RECORD_FORCES) && !h->fsm_on && h->debug_steps < 0 && !h->stamps && !h->geo_stamps &&
-        h->n_t >= 4)
-        return run_fused(h, ticks, flags, carry, fused_geo);
+    if (sym && fusable) return run_fused(h, ticks, flags, carry, fused_geo);
     // ---- split tick of a shard: what needs only this rank's rows first (sfm_tick_begin), the rest once the exchange is in
     //      (sfm_tick_end).  Anything else: sfm_tick_begin does nothing and sfm_tick_end runs the whole tick.
     if (phase == PHASE_BEGIN) {

@@ -2592,7 +2592,7 @@ static void launch_fused_t(dim3 grid, bool geo, bool z3, const TickArgs& a, cons
 }
 
 hipError_t launch_fused_tick(bool rad, const TickArgs& a, const FusedArgs& f, hipStream_t st, int nw) {
-    if (a.N <= 1 || f.n_g < 2) return hipErrorInvalidValue;
+    if (a.N <= 1 || f.n_g < 1) return hipErrorInvalidValue;
     const bool geo = f.n_geo_wg > 0, z3 = f.slabz_next != nullptr;
     const int n_adv = (geo && a.adv.M > 0) ? (a.adv.M + nw - 1) / nw : 0;
     const dim3 grid(f.n_geo_wg + f.n_pair_wg + n_adv);

@@ -828,7 +828,7 @@ def _fused_resync_rounds(eng, sc, prm, n_ticks, row_blocks, seed, world_side, th
     return variant, worst_v, worst_x, int(draws.sum())
 
 
-@pytest.mark.parametrize("n,use_radius,coincide,z_spread", [(256, False, False, 0.0), (300, True, False, 0.0), (1000, False, True, 0.0), (4160, False, False, 0.0),
+@pytest.mark.parametrize("n,use_radius,coincide,z_spread", [(2, False, False, 0.0), (64, False, False, 0.0), (130, True, False, 1.5), (256, False, False, 0.0), (300, True, False, 0.0), (1000, False, True, 0.0), (4160, False, False, 0.0),
                                                             (300, True, False, 1.5), (1000, False, True, 1.5), (4096, False, False, 1.5)])
 def test_fused_tick_pinned_to_the_oracle(n, use_radius, coincide, z_spread, monkeypatch):
     """sfm_fused_tick_kernel -- the kernel bench.py times on c2 -- against the ORACLE directly, re-synchronised every tick
@@ -891,7 +891,7 @@ def _geo_engine(sc, cfg):
     return eng
 
 
-@pytest.mark.parametrize("n,z_spread", [(512, 0.0), (1000, 0.0), (2048, 0.0), (4096, 0.0), (1000, 1.5), (4096, 1.5)])
+@pytest.mark.parametrize("n,z_spread", [(64, 0.0), (200, 1.5), (512, 0.0), (1000, 0.0), (2048, 0.0), (4096, 0.0), (1000, 1.5), (4096, 1.5)])
 def test_fused_tick_with_border_and_obstacle_forces_pinned_to_the_oracle(n, z_spread, monkeypatch):
     """Round 3: crowds below the list cutoff WITH border / obstacle forces take the fused tick too -- geometry workgroups are a
     second role of sfm_fused_tick_kernel, vehicles that move on the device a third (forces.py:138-283, obstacles.py:297-329).
@@ -905,7 +905,7 @@ def test_fused_tick_with_border_and_obstacle_forces_pinned_to_the_oracle(n, z_sp
     try:
         loc, vel, wp = sc.loc.copy(), sc.vel.copy(), sc.waypoint.copy()
         crossing = np.zeros(n, bool)
-        blocks = ((0, n),) if n <= 1000 else ((0, 128), (n // 2 - 64, n // 2 + 64), (n - 128, n))
+        blocks = ((0, n),) if n <= 1000 else ((0, 128), (n // 2 - 64, n // 2 + 64), (n - 128, n))       # (crowds under 256: device-resident runs take the fused tick too)
         worst = 0.0
         for k in range(6):
             for (c_d, r_d), (c_h, r_h) in zip(eng.dynamic_obstacles(), sc.dynamic_obstacles):
@@ -934,7 +934,7 @@ def test_fused_tick_with_border_and_obstacle_forces_pinned_to_the_oracle(n, z_sp
         eng.close()
 
 
-@pytest.mark.parametrize("n,use_radius,z_spread", [(700, False, 0.0), (2500, True, 0.0), (4096, False, 0.0), (2500, False, 1.5), (4096, True, 1.5)])
+@pytest.mark.parametrize("n,use_radius,z_spread", [(700, False, 0.0), (2500, True, 0.0), (4096, False, 0.0), (6000, False, 0.0), (2500, False, 1.5), (4096, True, 1.5)])
 def test_fused_run_with_border_and_obstacle_forces_matches_the_two_launch_tick(n, use_radius, z_spread, monkeypatch):
     """The CARRIED path of the same: inside one sfm_run the geometry workgroups of launch k evaluate the state launch k has just
     integrated, against the vehicles launch k-1 moved on (ping-pong), across device re-packs (every 5 ticks here: each followed by a
