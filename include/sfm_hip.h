@@ -163,10 +163,12 @@ int sfm_download_modes(SfmHandle* h, uint8_t* mode, float* target_speed, int32_t
 int sfm_tick(SfmHandle* h, uint32_t flags);
 /* `ticks` ticks back to back without host intervention (device-resident loop for benchmarks and the
  * CARLA-free harness; the loop of run_simulation.py:212-221 without the simulator); flags as above,
- * SFM_TICK_INTEGRATE is implied.  A whole planar crowd with only the acceleration and pedestrian forces
- * takes one launch per tick here (sfm_fused_tick_kernel), and consecutive sfm_run /
- * sfm_tick calls with no other call on the handle in between keep that up across calls; results are
- * those of `ticks` calls of sfm_tick up to the order of the fp32 sums (tested to <= 1e-5). */
+ * SFM_TICK_INTEGRATE is implied.  A whole crowd of fewer than 8192 pedestrians -- planar or 3-D, with or
+ * without border / obstacle forces and vehicles that move on the device -- takes ONE launch per tick here
+ * (sfm_fused_tick_kernel) whatever `ticks` is, so what a run computes does not depend on how
+ * the caller cuts it into calls; consecutive sfm_run / sfm_tick calls with no other call on the handle in
+ * between carry on without the launch in front.  Results are those of `ticks` calls of sfm_tick up to the
+ * order of the fp32 sums (each tick checked against the oracle to <= 1e-5). */
 int sfm_run(SfmHandle* h, int ticks, uint32_t flags);
 /* One integrating tick of a SHARD in two halves, so that the exchange of the previous tick's rows (the one all-gather per tick
  * of SURVEY.md section 8e; no reference counterpart, the reference is single-process) can run beside the part that does not
