@@ -934,6 +934,43 @@ def test_fused_tick_with_border_and_obstacle_forces_pinned_to_the_oracle(n, z_sp
         eng.close()
 
 
+@pytest.mark.parametrize("forces", [("pedestrian_force", "border_force"), ("pedestrian_force", "static_obstacle_force"),
+                                    ("pedestrian_force", "dynamic_obstacle_force"), ("acceleration_force", "pedestrian_force", "dynamic_obstacle_force"),
+                                    ("acceleration_force", "pedestrian_force", "border_force", "static_obstacle_force")],
+                         ids=lambda f: "+".join(x.split("_")[0] for x in f))
+def test_fused_tick_with_every_subset_of_the_geometry_forces(forces, monkeypatch):
+    """The one-launch tick with each kind of geometry force on its own (the disabled kinds' workgroups find nothing; a crowd
+    without the acceleration force coasts), re-synchronised against the oracle every tick; a pedestrian in CROSSING_ROAD mode
+    feels no border force (forces.py:176-177)."""
+    n = 700
+    sc = _geo_scenario(n, 4400)
+    cfg = default_sfm_config(forces)
+    prm = O.OracleParams.from_config(cfg)
+    crossing = np.zeros(n, bool); crossing[::9] = True
+    eng = SfmEngine(cfg, 0.05)
+    try:
+        eng.set_borders(sc.borders, sc.border_centers, sc.border_lengths)
+        eng.set_static_obstacles(sc.static_obstacles)
+        eng.set_dynamic_boxes([c for c, _ in sc.dynamic_obstacles], sc.dynamic_yaw, sc.dynamic_extent, sc.dynamic_vel)
+        eng.upload_state(sc.loc, sc.vel, sc.waypoint, sc.target_speed, sc.radius, crossing)
+        eng.set_waypoint_stream(sc.seed, sc.world_side, 2.0)
+        loc, vel, wp = sc.loc.copy(), sc.vel.copy(), sc.waypoint.copy()
+        for k in range(4):
+            geom = O.Geometry(sc.borders, sc.border_centers, sc.border_lengths, sc.static_obstacles, sc.dynamic_obstacles, sc.dynamic_vel)
+            with np.errstate(all="ignore"):
+                _, _, v_new, expo, absum = c_oracle.tick(loc, vel, wp, sc.target_speed, sc.radius, crossing, geom, prm, 0.05, theta_tol=P.THETA_TOL)
+            eng.run(1, redraw=True)
+            assert "fused" in eng.kernel_variant(), eng.kernel_variant()
+            dloc, dvel, dwp = eng.state()
+            P.check_velocity_conditioned(dvel, v_new, expo, absum, 0.05)
+            loc, vel = dloc, dvel
+            wp = np.concatenate([dwp, np.zeros((n, 1))], axis=1)
+            if "dynamic_obstacle_force" in forces:
+                scenarios.advance_dynamic(sc, 0.05)            # (the vehicles only live on the device when their force is on)
+    finally:
+        eng.close()
+
+
 @pytest.mark.parametrize("n,use_radius,z_spread", [(700, False, 0.0), (2500, True, 0.0), (4096, False, 0.0), (6000, False, 0.0), (2500, False, 1.5), (4096, True, 1.5)])
 def test_fused_run_with_border_and_obstacle_forces_matches_the_two_launch_tick(n, use_radius, z_spread, monkeypatch):
     """The CARRIED path of the same: inside one sfm_run the geometry workgroups of launch k evaluate the state launch k has just

@@ -268,3 +268,35 @@ def test_block_layout_of_the_ranks():
     assert block_layout(8, (8, 1)) == (8, 1)
     with pytest.raises(ValueError):
         block_layout(4, (8, 1))
+
+
+def test_bench_flags_counters_from_another_build_as_stale(tmp_path, monkeypatch):
+    """bench.py's roofline multiplies committed PMC counters by a live launch time; the summary carries the git blob id of
+    sfm_kernels.hip at collection time and the line must say `counters_stale` when the loaded build's source differs
+    (round-2 verdict, bench hygiene).  The blob id is git's own (`git hash-object`), computed without a .git directory."""
+    import hashlib
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    src = tmp_path / "kernels.hip"
+    src.write_bytes(b"__global__ void k() {}\n")
+    blob = hashlib.sha1(b"blob %d\0" % len(src.read_bytes()) + src.read_bytes()).hexdigest()
+    assert bench.git_blob_sha1(str(src)) == blob
+    assert bench.git_blob_sha1(str(tmp_path / "missing")) is None
+    summary = tmp_path / "pmc.csv"
+    summary.write_text(f"# rocprofv3 --pmc means per launch; sfm_kernels.hip git-blob {blob}\n"
+                       "workload,kernel,counter,mean_per_launch,launches\nc2,sfm_fused_tick_kernel,SQ_INSTS_VALU,100.000,5\n")
+    monkeypatch.setattr(bench, "PMC_SUMMARY", str(summary))
+    monkeypatch.setattr(bench, "KERNEL_SOURCE", str(src))
+    pmc, stamp = bench.pmc_counters("c2", "sfm_fused_tick_kernel")
+    assert pmc == {"SQ_INSTS_VALU": 100.0} and stamp["counters_stale"] is False
+    src.write_bytes(b"__global__ void k() { }\n")                    # the kernels were edited after the counter passes
+    assert bench.pmc_counters("c2", "sfm_fused_tick_kernel")[1]["counters_stale"] is True
+    assert bench.pmc_counters("c9", "nothing")[0] == {}
+    # the committed summary belongs to the committed kernels
+    monkeypatch.undo()
+    pmc, stamp = bench.pmc_counters("c2", "sfm_fused_tick_kernel")
+    assert "SQ_INSTS_VALU" in pmc and "VALU_PER_64_PAIR_STEP" in pmc and stamp["counters_stale"] is False
