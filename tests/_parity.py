@@ -90,3 +90,19 @@ def diagnostics(got, ref, absum, plain, expo):
             # per pedestrian against the UNWEIGHTED sum of its term magnitudes (what fp32 rounding of the sum is relative to),
             # discontinuity allowance taken off: stays meaningful when |F_i| itself is a small difference of large terms
             "row_over_terms_max": float(np.max(np.maximum(err - np.nan_to_num(expo[ok]) * 1.001 - ATOL, 0.0) / np.maximum(pl, 1e-300))) if err.size else 0.0}
+
+
+def geometry_tie_exposure(O, loc, vel, waypoint, target_speed, radius, crossing, geom, prm):
+    """Exposure of the border / obstacle forces to decisions within fp32 noise of their thresholds -- argmin ties between two
+    sampled points, strict-< culls (forces.py:149-155, 222-229) -- from the NumPy oracle, which models them (``tie_rel``); the C
+    oracle that the large tests use for speed only models the sign(theta) / wrap exposures.  Cheap: O(N x polylines), the
+    pedestrian force is switched off for this call.  Add it to the C oracle's exposure."""
+    import copy
+    geo_only = copy.copy(prm)
+    geo_only.enabled = dict(prm.enabled, pedestrian_force=False, acceleration_force=False)
+    if not any(geo_only.enabled.values()):
+        return np.zeros(len(loc))
+    diag = {}
+    with np.errstate(all="ignore"):
+        O.tick_forces(loc, vel, waypoint, target_speed, radius, crossing, geom, geo_only, theta_tol=THETA_TOL, tie_rel=TIE_REL, diag=diag)
+    return np.nan_to_num(diag["total"][0])

@@ -458,6 +458,52 @@ def test_golden_z_spread_case_through_the_symmetric_kernel(monkeypatch):
         eng.close()
 
 
+@pytest.mark.parametrize("seed", range(24))
+def test_randomised_device_resident_runs_vs_oracle(seed):
+    """Twenty-four random scenarios through sfm_run (the one-launch tick for everything under 8192 pedestrians): N from 2 to
+    3000, any subset of the forces that includes the pedestrian force, planar or 3-D, with or without use_ped_radius, vehicles on the
+    device or none -- three ticks, each re-synchronised against the oracle (conditioned v' tolerance: random obstacle layouts
+    produce the cancellations it exists for)."""
+    rng = np.random.default_rng(9000 + seed)
+    n = int(rng.choice([2, 3, 17, 64, 65, 130, 255, 256, 300, 640, 1000, 1500, 3000]))
+    forces = ["pedestrian_force"] + [f for f in ("acceleration_force", "border_force", "static_obstacle_force", "dynamic_obstacle_force")
+                                    if rng.random() < 0.6]
+    z_spread = float(rng.choice([0.0, 0.0, 1.2]))
+    use_radius = bool(rng.random() < 0.3)
+    nb, ns, nd = int(rng.integers(0, 40)), int(rng.integers(0, 12)), int(rng.integers(0, 6))
+    sc = scenarios.make_scenario(n, 100 + seed, n_borders=nb, n_static=ns, n_dynamic=nd, z_spread=z_spread,
+                                 density=0.25 if use_radius else float(rng.choice([0.25, 1.0])), border_len=(5.0, 25.0))
+    cfg = default_sfm_config(tuple(forces))
+    cfg["use_ped_radius"] = use_radius
+    prm = O.OracleParams.from_config(cfg)
+    crossing = rng.random(n) < 0.1
+    eng = SfmEngine(cfg, 0.05)
+    try:
+        if nb:
+            eng.set_borders(sc.borders, sc.border_centers, sc.border_lengths)
+        eng.set_static_obstacles(sc.static_obstacles)
+        if nd:
+            eng.set_dynamic_boxes([c for c, _ in sc.dynamic_obstacles], sc.dynamic_yaw, sc.dynamic_extent, sc.dynamic_vel)
+        eng.upload_state(sc.loc, sc.vel, sc.waypoint, sc.target_speed, sc.radius, crossing)
+        eng.set_waypoint_stream(sc.seed, sc.world_side, 2.0)
+        loc, vel, wp = sc.loc.copy(), sc.vel.copy(), sc.waypoint.copy()
+        for k in range(3):
+            geom = O.Geometry(sc.borders, sc.border_centers, sc.border_lengths, sc.static_obstacles, sc.dynamic_obstacles, sc.dynamic_vel)
+            with np.errstate(all="ignore"):
+                _, _, v_new, expo, absum = c_oracle.tick(loc, vel, wp, sc.target_speed, sc.radius, crossing, geom, prm, 0.05, theta_tol=P.THETA_TOL)
+            expo = expo + P.geometry_tie_exposure(O, loc, vel, wp, sc.target_speed, sc.radius, crossing, geom, prm)   # argmin ties, culls at their threshold
+            eng.run(1, redraw=True)
+            assert "fused" in eng.kernel_variant(), (eng.kernel_variant(), n, forces)
+            dloc, dvel, dwp = eng.state()
+            P.check_velocity_conditioned(dvel, v_new, expo, absum, 0.05)
+            loc, vel = dloc, dvel
+            wp = np.concatenate([dwp, np.zeros((n, 1))], axis=1)
+            if nd:
+                scenarios.advance_dynamic(sc, 0.05)
+    finally:
+        eng.close()
+
+
 def test_cap_velocity_properties():
     """stateutils.cap_velocity: |v'| <= 1.3*v_target; zero target -> zero velocity."""
     n = 512
@@ -911,6 +957,7 @@ def test_fused_tick_with_border_and_obstacle_forces_pinned_to_the_oracle(n, z_sp
             for (c_d, r_d), (c_h, r_h) in zip(eng.dynamic_obstacles(), sc.dynamic_obstacles):
                 assert np.array_equal(c_d, c_h) and np.array_equal(r_d, r_h), f"vehicles at tick {k}"
             geom = O.Geometry(sc.borders, sc.border_centers, sc.border_lengths, sc.static_obstacles, sc.dynamic_obstacles, sc.dynamic_vel)
+            tie_expo = P.geometry_tie_exposure(O, loc, vel, wp, sc.target_speed, sc.radius, crossing, geom, prm)   # argmin ties, culls at their threshold
             eng.run(1, redraw=True)
             assert "fused_tick_kernel(geo)" in eng.kernel_variant(), eng.kernel_variant()
             dloc, dvel, dwp = eng.state()
@@ -919,6 +966,7 @@ def test_fused_tick_with_border_and_obstacle_forces_pinned_to_the_oracle(n, z_sp
                     _, _, v_new, expo, absum = c_oracle.tick(loc, vel, wp, sc.target_speed, sc.radius, crossing, geom, prm, 0.05, rows=r,
                                                              theta_tol=P.THETA_TOL)
                 sl = slice(r[0], r[1])
+                expo = expo + tie_expo[sl]
                 P.check_velocity_conditioned(dvel[sl], v_new, expo, absum, 0.05)
                 worst = max(worst, float(np.max(np.linalg.norm(dvel[sl] - v_new, axis=1) / np.maximum(np.linalg.norm(v_new, axis=1), 1e-12))))
                 x_new = loc[sl] + 0.05 * v_new
@@ -959,6 +1007,7 @@ def test_fused_tick_with_every_subset_of_the_geometry_forces(forces, monkeypatch
             geom = O.Geometry(sc.borders, sc.border_centers, sc.border_lengths, sc.static_obstacles, sc.dynamic_obstacles, sc.dynamic_vel)
             with np.errstate(all="ignore"):
                 _, _, v_new, expo, absum = c_oracle.tick(loc, vel, wp, sc.target_speed, sc.radius, crossing, geom, prm, 0.05, theta_tol=P.THETA_TOL)
+            expo = expo + P.geometry_tie_exposure(O, loc, vel, wp, sc.target_speed, sc.radius, crossing, geom, prm)
             eng.run(1, redraw=True)
             assert "fused" in eng.kernel_variant(), eng.kernel_variant()
             dloc, dvel, dwp = eng.state()
