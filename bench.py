@@ -317,7 +317,7 @@ def main():
     kernel_us = eng.engine.profile_dominant_kernel(reps)
     kernel_us_end = kernel_us
     state_note = "end of the timed run"
-    if world == 1 and sc.n >= 8192 and "pedestrian_force" in forces:
+    if world == 1 and sc.n > 4096 and "pedestrian_force" in forces:
         # a cutoff is on: the launch that goes with the committed counters is the one PMC_STATE_TICKS ticks after the upload
         e2 = HipShardEngine(cfg, dt, device=local)
         e2.load(sc)

@@ -118,7 +118,7 @@ struct SfmHandle {
     uint32_t* work = nullptr;
     int* work_count = nullptr;
     size_t work_cap = 0;
-    int cut_mode = -1;                     // SFM_CUTOFF: 0 off, 1 on, -1 auto (on for N >= 8192)
+    int cut_mode = -1;                     // SFM_CUTOFF: 0 off, 1 on, -1 auto (on above AUTO_CUTOFF_N pedestrians)
     unsigned long long* stamps = nullptr;  // SFM_STAMPS diagnostic: per-workgroup timestamps of the symmetric pair kernel
     unsigned long long* geo_stamps = nullptr;   // SFM_GEO_STAMPS diagnostic: per-workgroup phase stamps of the geometry kernel
     // spatial reordering: row s holds the caller's pedestrian perm[s] (strips in x, each sorted by y: sfm_reorder.hip), so the 64-tiles
@@ -927,6 +927,13 @@ static void pick_shape(const SfmHandle* h, int n_local, int* ipw, int* team) {
     *team = t;
 }
 
+// Above this many pedestrians the tile-pair list cutoff is on by default (and with it the two- / three-launch tick); up to it a
+// device-resident run is one launch per tick on the fused kernel, whose 512 workgroups of 16 waves are exactly one residency round
+// at N = 4096 -- one more group and a second round starts.  Measured (tools/threshold_probe.py, 0.25 ped/m2, us per tick, fused /
+// list cutoff): N = 4096 16.3 / 24.1, 5120 29.2 / 27.6, 6144 37.1 / 31.6, 8000 56.5 / 40.7; with border / obstacle forces 21.5 / 25.5,
+// 31.3 / 25.5, 41.3 / 27.9, 59.9 / 28.2.  (Rounds 1-2 switched at 8192.)
+constexpr int AUTO_CUTOFF_N = 4096;
+
 static void fill_args(SfmHandle* h, TickArgs& a, uint32_t flags) {
     const SfmParams& p = h->prm;
     memset(&a, 0, sizeof(a));
@@ -956,13 +963,13 @@ static void fill_args(SfmHandle* h, TickArgs& a, uint32_t flags) {
     a.adv = DynAdvance{h->dynamics.ctr, h->dynamics.off, h->dyn_local, h->dyn_rot, h->dynamics.pts,
                        (h->dyn_boxes && (flags & SFM_TICK_INTEGRATE)) ? h->dynamics.K : 0, h->prm.step_length, 0};
     const bool cut = p.enabled[SFM_FORCE_PEDESTRIAN] && h->tile_box && h->N <= 64 * 64 * WAVE &&
-                     (h->cut_mode == 1 || (h->cut_mode < 0 && h->N >= 8192)) && p.pedestrian.gamma > 0.f && p.pedestrian.lambda >= 0.f;
+                     (h->cut_mode == 1 || (h->cut_mode < 0 && h->N > AUTO_CUTOFF_N)) && p.pedestrian.gamma > 0.f && p.pedestrian.lambda >= 0.f;
     a.tile_box = cut ? h->tile_box + (size_t)h->box_cur * h->n_t : nullptr;
     a.tile_vmax = cut ? h->tile_vmax + (size_t)h->box_cur * h->n_t : nullptr;
     // whole crowd on the symmetric path: the epilogue leaves the next tick's boxes and a zeroed list counter, so the next tick starts
     // with its list kernel instead of a bounds kernel and a memset (the boxes do not depend on the radii -- cut_pad carries 2 r_max
     // into every test -- and a 3-D crowd's largest speed includes v_z)
-    // (a cutoff for crowds under 8192 -- workgroups testing their own tile pair, a cost-balanced deal of the items -- was built and
+    // (a cutoff for small crowds -- workgroups testing their own tile pair, a cost-balanced deal of the items -- was built and
     //  measured in round 2: on c2 it cost as much in boxes, dealer and re-packs as it saved in steps.  Removed in round 3)
     const bool carry = cut && h->slab && h->i_begin == 0 && h->i_end == h->N && h->sym_mode != 0 && h->carry_mode != 0 && !h->fsm_on;
     a.tile_box_out = carry ? h->tile_box + (size_t)(h->box_cur ^ 1) * h->n_t : nullptr;

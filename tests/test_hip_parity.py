@@ -460,7 +460,7 @@ def test_golden_z_spread_case_through_the_symmetric_kernel(monkeypatch):
 
 @pytest.mark.parametrize("seed", range(24))
 def test_randomised_device_resident_runs_vs_oracle(seed):
-    """Twenty-four random scenarios through sfm_run (the one-launch tick for everything under 8192 pedestrians): N from 2 to
+    """Twenty-four random scenarios through sfm_run (the one-launch tick for everything up to 4096 pedestrians): N from 2 to
     3000, any subset of the forces that includes the pedestrian force, planar or 3-D, with or without use_ped_radius, vehicles on the
     device or none -- three ticks, each re-synchronised against the oracle (conditioned v' tolerance: random obstacle layouts
     produce the cancellations it exists for)."""
@@ -795,6 +795,7 @@ def test_fused_tick_matches_the_two_kernel_tick(n, use_radius, coincide, monkeyp
         sc.loc[5] = sc.loc[6]                                 # ... and two of the same tile
     cfg = default_sfm_config(("acceleration_force", "pedestrian_force"))
     cfg["use_ped_radius"] = use_radius
+    monkeypatch.setenv("SFM_CUTOFF", "0")                     # (above 4096 pedestrians the list cutoff is on by default, and with it the two-launch tick)
     out = {}
     for tag, fused in (("fused", "1"), ("again", "1"), ("two-kernel", "0")):
         monkeypatch.setenv("SFM_FUSED", fused)
@@ -891,6 +892,7 @@ def test_fused_tick_pinned_to_the_oracle(n, use_radius, coincide, z_spread, monk
     prm = O.OracleParams.from_config(cfg)
     side = 0.3 * sc.world_side                                # a small waypoint square: arrivals inside 8 ticks
     monkeypatch.setenv("SFM_FUSED", "2")                      # a single sfm_run(1) takes the fused tick too (front launch + one integrating launch)
+    monkeypatch.setenv("SFM_CUTOFF", "0")                     # (N = 4160: odd tile and group counts; above 4096 the list cutoff would be on by default)
     eng = SfmEngine(cfg, 0.05)
     try:
         eng.upload_state(sc.loc, sc.vel, sc.waypoint, sc.target_speed, sc.radius, None)
@@ -1030,6 +1032,7 @@ def test_fused_run_with_border_and_obstacle_forces_matches_the_two_launch_tick(n
     cfg = default_sfm_config(scenarios.ALL_FORCES)
     cfg["use_ped_radius"] = use_radius
     monkeypatch.setenv("SFM_RESORT_EVERY", "5")
+    monkeypatch.setenv("SFM_CUTOFF", "0")                     # (N = 6000: the fused tick's 8-wave form with two slices; by default the list cutoff takes over above 4096)
     out = {}
     for tag, env in (("fused", "1"), ("again", "1"), ("split", "1"), ("two-launch", "0")):
         monkeypatch.setenv("SFM_FUSED", env)
