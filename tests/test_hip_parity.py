@@ -891,7 +891,7 @@ def test_fused_tick_pinned_to_the_oracle(n, use_radius, coincide, z_spread, monk
     cfg["use_ped_radius"] = use_radius
     prm = O.OracleParams.from_config(cfg)
     side = 0.3 * sc.world_side                                # a small waypoint square: arrivals inside 8 ticks
-    monkeypatch.setenv("SFM_FUSED", "2")                      # a single sfm_run(1) takes the fused tick too (front launch + one integrating launch)
+    monkeypatch.setenv("SFM_FUSED", "1")                      # (the default: every sfm_run, also a single sfm_run(1), is launch in front + integrating launches)
     monkeypatch.setenv("SFM_CUTOFF", "0")                     # (N = 4160: odd tile and group counts; above 4096 the list cutoff would be on by default)
     eng = SfmEngine(cfg, 0.05)
     try:
@@ -912,7 +912,7 @@ def test_fused_tick_pinned_to_the_oracle_at_c2(monkeypatch):
     prm = O.OracleParams.from_config(cfg)
     n = sc.n
     blocks = ((0, 128), (n // 2 - 64, n // 2 + 64), (n - 128, n))
-    monkeypatch.setenv("SFM_FUSED", "2")
+    monkeypatch.setenv("SFM_FUSED", "1")
     eng = SfmEngine(cfg, 0.05)
     try:
         eng.upload_state(sc.loc, sc.vel, sc.waypoint, sc.target_speed, sc.radius, None)
@@ -948,7 +948,7 @@ def test_fused_tick_with_border_and_obstacle_forces_pinned_to_the_oracle(n, z_sp
     sc = _geo_scenario(n, 6100 + n, z_spread)
     cfg = default_sfm_config(scenarios.ALL_FORCES)
     prm = O.OracleParams.from_config(cfg)
-    monkeypatch.setenv("SFM_FUSED", "2")                      # a single sfm_run(1) takes the fused tick (launch in front + one integrating launch)
+    monkeypatch.setenv("SFM_FUSED", "1")                      # (the default: a single sfm_run(1) is the launch in front + one integrating launch)
     eng = _geo_engine(sc, cfg)
     try:
         loc, vel, wp = sc.loc.copy(), sc.vel.copy(), sc.waypoint.copy()
