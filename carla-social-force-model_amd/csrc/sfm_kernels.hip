@@ -473,7 +473,7 @@ struct GeoTile { float x0, y0, x1, y1, cx, cy, half_diag, skip_max; };
 // returns how many were kept.  SCAN = true (list overflow): the kept polylines beyond GEO_ITEMS are scanned on the spot.
 template <bool RAD, bool SCAN>
 __device__ __forceinline__ int geo_find(const TickArgs& a, const GeoLane& me, const GeoTile& tb, GeoItem* list, float2* row,
-                                        int lane, int gwave, int n_gwaves, float (&f)[6]) {
+                                        int lane, int gwave, int n_gwaves, float (&f)[6], int cap = GEO_ITEMS) {
     int n_found = 0;                                                   // uniform
     int dealt = 0;                                                     // polylines of the kinds before: the deal carries on where they ended
 #pragma unroll
@@ -518,7 +518,7 @@ __device__ __forceinline__ int geo_find(const TickArgs& a, const GeoLane& me, co
                 const bool keep = geo_keep(a, me, kind, it.c, it.s0, it.s1);
                 if (!__any(keep)) continue;
                 if (SCAN) {
-                    if (n_found >= GEO_ITEMS) geo_item<RAD>(a, me, it, keep, row, lane, f);
+                    if (n_found >= cap) geo_item<RAD>(a, me, it, keep, row, lane, f);
                 } else if (n_found < GEO_ITEMS && lane == 0) {
                     list[n_found] = it;
                 }
@@ -577,6 +577,9 @@ __device__ __forceinline__ void list_emit(bool keep, uint32_t item, uint32_t* __
     if (keep) work[s_n[wave] + __popcll(m & ((1ull << lane) - 1ull))] = item;
 }
 
+#ifndef GEO_DIRECT_PER_WAVE
+#define GEO_DIRECT_PER_WAVE 8
+#endif
 template <int GW>
 struct GeoShared {                              // LDS of one geometry workgroup: ~4 KiB per wave
     float2 row[GW][WAVE];
@@ -616,6 +619,16 @@ __device__ __forceinline__ void geometry_forces(const TickArgs& a, GeoShared<GW>
 
     // ---- phase 1: find
     const int gwave = slice * GW + wave, n_gwaves = GW * n_slices;       // small crowds: the tile's polylines are split over n_slices workgroups
+    // A few polylines per wave: every wave scans what it keeps on the spot -- no list, no barrier, no second deal (their fixed cost is
+    // most of a small crowd's geometry workgroup, whose waves hold at most a polyline or two each)
+    const int k_all = (a.en_border ? a.borders.K : 0) + (a.en_static ? a.statics.K : 0) + (a.en_dynamic ? a.dynamics.K : 0);
+    if (k_all <= GEO_DIRECT_PER_WAVE * n_gwaves) {
+        geo_find<RAD, true>(a, me, tb, sh.item[wave], row, lane, gwave, n_gwaves, f, 0);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) sh.acc[wave][q][lane] = f[q];
+        __syncthreads();
+        return;
+    }
     const int n_found = geo_find<RAD, false>(a, me, tb, sh.item[wave], row, lane, gwave, n_gwaves, f);
     if (lane == 0) sh.count[wave] = min(n_found, GEO_ITEMS);
     __syncthreads();
