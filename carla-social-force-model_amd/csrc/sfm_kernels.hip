@@ -591,7 +591,9 @@ struct GeoShared {                              // LDS of one geometry workgroup
 // The border / obstacle forces on the 64 pedestrians `me` (one per lane, the same in every wave of the workgroup), slice `slice` of
 // n_slices of the polylines: find, then scan.  Leaves every wave's partial sums in sh.acc[wave][6][lane]
 // ({border x, y, static x, y, dynamic x, y}, the obstacle terms still without their factor -A) behind a workgroup barrier.
-template <bool RAD, int GW>
+// DIRECT: the on-the-spot form below is compiled in (the fused tick's geometry workgroups; in the stand-alone geometry kernel and the
+// pair + geometry launch of the list-cutoff workloads the third inlined copy of the scan spills registers, and their crowds are large).
+template <bool RAD, int GW, bool DIRECT = false>
 __device__ __forceinline__ void geometry_forces(const TickArgs& a, GeoShared<GW>& sh, GeoLane& me, int slice, int n_slices, int tid,
                                                 unsigned long long* st1) {
     const int lane = tid & (WAVE - 1);
@@ -622,7 +624,7 @@ __device__ __forceinline__ void geometry_forces(const TickArgs& a, GeoShared<GW>
     // A few polylines per wave: every wave scans what it keeps on the spot -- no list, no barrier, no second deal (their fixed cost is
     // most of a small crowd's geometry workgroup, whose waves hold at most a polyline or two each)
     const int k_all = (a.en_border ? a.borders.K : 0) + (a.en_static ? a.statics.K : 0) + (a.en_dynamic ? a.dynamics.K : 0);
-    if (k_all <= GEO_DIRECT_PER_WAVE * n_gwaves) {
+    if (DIRECT && k_all <= GEO_DIRECT_PER_WAVE * n_gwaves) {
         geo_find<RAD, true>(a, me, tb, sh.item[wave], row, lane, gwave, n_gwaves, f, 0);
 #pragma unroll
         for (int q = 0; q < 6; ++q) sh.acc[wave][q][lane] = f[q];
@@ -2265,7 +2267,7 @@ __global__ __launch_bounds__(NW * WAVE, (NW == 8 && Z3) ? 6 : 8) void sfm_fused_
         me.walk = me.live && !(a.crossing && a.crossing[ig]);          // forces.py:140-141,176-177
         __syncthreads();                                               // the geometry body's LDS lies over the prologue's
         GeoShared<NW>& gs = *reinterpret_cast<GeoShared<NW>*>(smem);
-        geometry_forces<RAD, NW>(a, gs, me, geo_slice, f.geo_slices, tid, nullptr);
+        geometry_forces<RAD, NW, true>(a, gs, me, geo_slice, f.geo_slices, tid, nullptr);
         if (wave < 2 && me.live) {                                     // wave 0: x, wave 1: y -- border, static, dynamic in that order
             float vb = 0.f, vs = 0.f, vd = 0.f;
 #pragma unroll
