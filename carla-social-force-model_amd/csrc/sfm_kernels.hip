@@ -578,7 +578,7 @@ __device__ __forceinline__ void list_emit(bool keep, uint32_t item, uint32_t* __
 }
 
 #ifndef GEO_DIRECT_PER_WAVE
-#define GEO_DIRECT_PER_WAVE 8
+#define GEO_DIRECT_PER_WAVE 64
 #endif
 template <int GW>
 struct GeoShared {                              // LDS of one geometry workgroup: ~4 KiB per wave
@@ -591,8 +591,9 @@ struct GeoShared {                              // LDS of one geometry workgroup
 // The border / obstacle forces on the 64 pedestrians `me` (one per lane, the same in every wave of the workgroup), slice `slice` of
 // n_slices of the polylines: find, then scan.  Leaves every wave's partial sums in sh.acc[wave][6][lane]
 // ({border x, y, static x, y, dynamic x, y}, the obstacle terms still without their factor -A) behind a workgroup barrier.
-// DIRECT: the on-the-spot form below is compiled in (the fused tick's geometry workgroups; in the stand-alone geometry kernel and the
-// pair + geometry launch of the list-cutoff workloads the third inlined copy of the scan spills registers, and their crowds are large).
+// DIRECT: the on-the-spot form below is compiled in (the fused tick's geometry workgroups.  In the stand-alone geometry kernel and the
+// pair + geometry launch of the list-cutoff workloads the third inlined copy of the scan spills registers, their crowds have hundreds
+// of polylines per wave, and a variant build with it measured the same on c3 / c5 and on the host-in-the-loop tick).
 template <bool RAD, int GW, bool DIRECT = false>
 __device__ __forceinline__ void geometry_forces(const TickArgs& a, GeoShared<GW>& sh, GeoLane& me, int slice, int n_slices, int tid,
                                                 unsigned long long* st1) {
@@ -621,8 +622,9 @@ __device__ __forceinline__ void geometry_forces(const TickArgs& a, GeoShared<GW>
 
     // ---- phase 1: find
     const int gwave = slice * GW + wave, n_gwaves = GW * n_slices;       // small crowds: the tile's polylines are split over n_slices workgroups
-    // A few polylines per wave: every wave scans what it keeps on the spot -- no list, no barrier, no second deal (their fixed cost is
-    // most of a small crowd's geometry workgroup, whose waves hold at most a polyline or two each)
+    // Up to GEO_DIRECT_PER_WAVE polylines per wave (one trip of find per kind): every wave scans what it keeps on the spot -- no list,
+    // no barrier, no second deal.  Their fixed cost is most of a small crowd's geometry workgroup, and up to 26 polylines per wave
+    // the on-the-spot form measured 10-35 % better on the whole tick (tools/direct_scan_probe.py; more per wave: not measured)
     const int k_all = (a.en_border ? a.borders.K : 0) + (a.en_static ? a.statics.K : 0) + (a.en_dynamic ? a.dynamics.K : 0);
     if (DIRECT && k_all <= GEO_DIRECT_PER_WAVE * n_gwaves) {
         geo_find<RAD, true>(a, me, tb, sh.item[wave], row, lane, gwave, n_gwaves, f, 0);
