@@ -1067,12 +1067,17 @@ static int fused_launch(SfmHandle* h, uint32_t flags, int mode, int* sl) {
     int slices = 0, nw = h->fused_waves;
     const int n_pair = fused_pair_workgroups(n_g);
     if (geo) {
-        slices = h->fused_geo_slices > 0 ? std::min(4, h->fused_geo_slices) : (h->n_t <= 64 ? 4 : 2);
+        // a geometry workgroup's time is the longest chain of kept polylines on one of its waves (each a dependent load -> scan), so
+        // more slices = more waves per tile pay as long as every workgroup of the launch still gets a CU of its own: up to 8 from
+        // 6 tiles on (all forces, N = 512 / 1024: 11.4 / 12.5 -> 10.9 / 11.3 us; N = 64 / 256: no change; 8 at N = 2048: 12.1 -> 15.1)
+        slices = h->n_t <= 64 ? 4 : 2;
+        if (h->n_t >= 6) slices = std::max(slices, std::min(FUSED_GEO_SLICES_MAX, (256 - n_pair) / h->n_t));
+        if (h->fused_geo_slices > 0) slices = std::min(FUSED_GEO_SLICES_MAX, h->fused_geo_slices);
         // two 16-wave workgroups fill a CU: when pair + geometry workgroups do not fit in 512 such slots the launch runs 8-wave
         // workgroups (four per CU; the pair phase is within a few per cent at 4 waves per SIMD)
         if (n_pair + h->n_t * slices > 512) nw = 8;
     }
-    const size_t grow = (size_t)4 * (size_t)h->N_pad;
+    const size_t grow = (size_t)FUSED_GEO_SLICES_MAX * (size_t)h->N_pad;
     // device-side vehicles: this launch's geometry workgroups read the vehicles at the time of the state they evaluate; its vehicle
     // workgroups write the next tick's into the other half.  Launch in front (mode 0): reads the stored ones, writes the alternate.
     // An integrating launch evaluates the NEXT state: reads the alternate, overwrites the stored half -- and then they swap.
@@ -1107,7 +1112,7 @@ static int fused_reserve(SfmHandle* h) {
     if (need > h->fslab_cap) { HIP_TRY(h, dev_realloc(h->fslab, need)); h->fslab_cap = need; }
     if (h->z3 && need > h->fslabz_cap) { HIP_TRY(h, dev_realloc(h->fslabz, need)); h->fslabz_cap = need; }
     if (h->own_alt_cap < h->cap) { HIP_TRY(h, dev_realloc(h->own_alt, (size_t)h->cap)); h->own_alt_cap = h->cap; }   // same size as own: they swap
-    const size_t gneed = (size_t)2 * 4 * (size_t)h->N_pad;
+    const size_t gneed = (size_t)2 * FUSED_GEO_SLICES_MAX * (size_t)h->N_pad;
     if (gneed > h->fgeo_cap) { HIP_TRY(h, dev_realloc(h->fgeo, gneed)); h->fgeo_cap = gneed; }
     if (h->dyn_boxes && h->dynamics.K > 0) {             // the vehicles' other half: same capacities as the stored one (they swap)
         if (h->dyn_ctr_alt_cap != h->dynamics.ctr_cap) { HIP_TRY(h, dev_realloc(h->dyn_ctr_alt, std::max<size_t>(1, h->dynamics.ctr_cap))); h->dyn_ctr_alt_cap = h->dynamics.ctr_cap; }

@@ -2089,10 +2089,11 @@ __global__ __launch_bounds__(NW * WAVE, (NW == 8 && Z3) ? 6 : 8) void sfm_fused_
         if (live && integrate) {
             o = f.own_cur[i];
             if (GEO) {
-                float2 gv[4];
+                float2 gv[FUSED_GEO_SLICES_MAX];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) gv[k] = k < f.geo_slices ? f.geo_prev[(size_t)k * a.N_pad + i] : make_float2(0.f, 0.f);
-                geo_f = make_float2((gv[0].x + gv[1].x) + (gv[2].x + gv[3].x), (gv[0].y + gv[1].y) + (gv[2].y + gv[3].y));
+                for (int k = 0; k < FUSED_GEO_SLICES_MAX; ++k) gv[k] = k < f.geo_slices ? f.geo_prev[(size_t)k * a.N_pad + i] : make_float2(0.f, 0.f);
+                geo_f = make_float2(((gv[0].x + gv[1].x) + (gv[2].x + gv[3].x)) + ((gv[4].x + gv[5].x) + (gv[6].x + gv[7].x)),
+                                    ((gv[0].y + gv[1].y) + (gv[2].y + gv[3].y)) + ((gv[4].y + gv[5].y) + (gv[6].y + gv[7].y)));
             }
             if ((a.flags & 2u) && diag_item) { nd0 = a.draws[i]; pid = a.ids ? a.ids[i] : (uint32_t)i; }
         }
