@@ -939,47 +939,77 @@ def _geo_engine(sc, cfg):
     return eng
 
 
-@pytest.mark.parametrize("n,z_spread", [(64, 0.0), (200, 1.5), (512, 0.0), (1000, 0.0), (2048, 0.0), (4096, 0.0), (1000, 1.5), (4096, 1.5)])
+def _geo_oracle_rounds(eng, sc, prm, n_ticks, blocks):
+    """n_ticks x ``eng.run(1, redraw=True)`` of a crowd with borders, static obstacles and vehicles that move on the device, every tick
+    re-synchronised against the oracle (v' through the conditioned 1e-5 check, x' to 1e-6), the device's vehicles against the host twin
+    bit for bit.  Returns the worst |dv'| / |v'|."""
+    n = sc.n
+    loc, vel, wp = sc.loc.copy(), sc.vel.copy(), sc.waypoint.copy()
+    crossing = np.zeros(n, bool)
+    worst = 0.0
+    for k in range(n_ticks):
+        for (c_d, r_d), (c_h, r_h) in zip(eng.dynamic_obstacles(), sc.dynamic_obstacles):
+            assert np.array_equal(c_d, c_h) and np.array_equal(r_d, r_h), f"vehicles at tick {k}"
+        geom = O.Geometry(sc.borders, sc.border_centers, sc.border_lengths, sc.static_obstacles, sc.dynamic_obstacles, sc.dynamic_vel)
+        tie_expo = P.geometry_tie_exposure(O, loc, vel, wp, sc.target_speed, sc.radius, crossing, geom, prm)   # argmin ties, culls at their threshold
+        eng.run(1, redraw=True)
+        assert "fused_tick_kernel(geo)" in eng.kernel_variant(), eng.kernel_variant()
+        dloc, dvel, dwp = eng.state()
+        for r in blocks:
+            with np.errstate(all="ignore"):
+                _, _, v_new, expo, absum = c_oracle.tick(loc, vel, wp, sc.target_speed, sc.radius, crossing, geom, prm, 0.05, rows=r,
+                                                         theta_tol=P.THETA_TOL)
+            sl = slice(r[0], r[1])
+            expo = expo + tie_expo[sl]
+            P.check_velocity_conditioned(dvel[sl], v_new, expo, absum, 0.05)
+            worst = max(worst, float(np.max(np.linalg.norm(dvel[sl] - v_new, axis=1) / np.maximum(np.linalg.norm(v_new, axis=1), 1e-12))))
+            x_new = loc[sl] + 0.05 * v_new
+            if eng.planar:
+                x_new[:, 2] = loc[sl, 2]
+            allow = 1e-6 * np.maximum(1.0, np.abs(x_new).max(axis=1)) + 0.05 * (1e-5 * 0.05 * absum + 0.05 * expo * 1.001)
+            assert (np.abs(dloc[sl] - x_new).max(axis=1) <= allow).all(), f"x' at tick {k}"
+        loc, vel = dloc, dvel
+        wp = np.concatenate([dwp, np.zeros((n, 1))], axis=1)
+        scenarios.advance_dynamic(sc, 0.05)
+    return worst
+
+
+@pytest.mark.parametrize("n,z_spread", [(64, 0.0), (200, 1.5), (512, 0.0), (1000, 0.0), (1500, 0.0), (2048, 0.0), (4096, 0.0), (1000, 1.5), (4096, 1.5)])
 def test_fused_tick_with_border_and_obstacle_forces_pinned_to_the_oracle(n, z_spread, monkeypatch):
     """Round 3: crowds below the list cutoff WITH border / obstacle forces take the fused tick too -- geometry workgroups are a
     second role of sfm_fused_tick_kernel, vehicles that move on the device a third (forces.py:138-283, obstacles.py:297-329).
     Every tick re-synchronised against the oracle (v' 1e-5, x' 1e-6), the device's vehicles against the host twin bit for bit;
-    N = 4096 runs the 8-wave form of the launch (pair + geometry workgroups do not fit in 512 slots of 16 waves)."""
+    N = 512 ... 1500 run eight geometry workgroups per tile, N = 4096 the 8-wave form of the launch (pair + geometry workgroups do not
+    fit in 512 slots of 16 waves)."""
     sc = _geo_scenario(n, 6100 + n, z_spread)
     cfg = default_sfm_config(scenarios.ALL_FORCES)
     prm = O.OracleParams.from_config(cfg)
     monkeypatch.setenv("SFM_FUSED", "1")                      # (the default: a single sfm_run(1) is the launch in front + one integrating launch)
     eng = _geo_engine(sc, cfg)
     try:
-        loc, vel, wp = sc.loc.copy(), sc.vel.copy(), sc.waypoint.copy()
-        crossing = np.zeros(n, bool)
         blocks = ((0, n),) if n <= 1000 else ((0, 128), (n // 2 - 64, n // 2 + 64), (n - 128, n))       # (crowds under 256: device-resident runs take the fused tick too)
-        worst = 0.0
-        for k in range(6):
-            for (c_d, r_d), (c_h, r_h) in zip(eng.dynamic_obstacles(), sc.dynamic_obstacles):
-                assert np.array_equal(c_d, c_h) and np.array_equal(r_d, r_h), f"vehicles at tick {k}"
-            geom = O.Geometry(sc.borders, sc.border_centers, sc.border_lengths, sc.static_obstacles, sc.dynamic_obstacles, sc.dynamic_vel)
-            tie_expo = P.geometry_tie_exposure(O, loc, vel, wp, sc.target_speed, sc.radius, crossing, geom, prm)   # argmin ties, culls at their threshold
-            eng.run(1, redraw=True)
-            assert "fused_tick_kernel(geo)" in eng.kernel_variant(), eng.kernel_variant()
-            dloc, dvel, dwp = eng.state()
-            for r in blocks:
-                with np.errstate(all="ignore"):
-                    _, _, v_new, expo, absum = c_oracle.tick(loc, vel, wp, sc.target_speed, sc.radius, crossing, geom, prm, 0.05, rows=r,
-                                                             theta_tol=P.THETA_TOL)
-                sl = slice(r[0], r[1])
-                expo = expo + tie_expo[sl]
-                P.check_velocity_conditioned(dvel[sl], v_new, expo, absum, 0.05)
-                worst = max(worst, float(np.max(np.linalg.norm(dvel[sl] - v_new, axis=1) / np.maximum(np.linalg.norm(v_new, axis=1), 1e-12))))
-                x_new = loc[sl] + 0.05 * v_new
-                if eng.planar:
-                    x_new[:, 2] = loc[sl, 2]
-                allow = 1e-6 * np.maximum(1.0, np.abs(x_new).max(axis=1)) + 0.05 * (1e-5 * 0.05 * absum + 0.05 * expo * 1.001)
-                assert (np.abs(dloc[sl] - x_new).max(axis=1) <= allow).all(), f"x' at tick {k}"
-            loc, vel = dloc, dvel
-            wp = np.concatenate([dwp, np.zeros((n, 1))], axis=1)
-            scenarios.advance_dynamic(sc, 0.05)
+        worst = _geo_oracle_rounds(eng, sc, prm, 6, blocks)
         print(f"\nfused tick with geometry vs oracle, N={n}: {eng.kernel_variant()}  worst |dv'|/|v'| {worst:.3g}")
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("n,n_borders,n_static,use_radius", [(64, 400, 100, False), (200, 1500, 200, True), (64, 4300, 100, False), (700, 40, 3000, False)])
+def test_fused_tick_geometry_scan_forms_pinned_to_the_oracle(n, n_borders, n_static, use_radius, monkeypatch):
+    """The two forms of the fused tick's geometry workgroups against the oracle, on small crowds with MANY polylines: up to 64
+    polylines per wave every wave scans what it keeps on the spot (8 and 27 per wave here, and 48 obstacle rings per wave), beyond
+    that find -> per-wave list -> dealt scan (69 per wave: 4400 polylines on one tile's 64 waves)."""
+    sc = scenarios.make_scenario(n, 6600 + n + n_borders, n_borders=n_borders, n_static=n_static, n_dynamic=6, border_len=(5.0, 25.0),
+                                 density=0.25 if use_radius else 1.0)
+    cfg = default_sfm_config(scenarios.ALL_FORCES)
+    cfg["use_ped_radius"] = use_radius
+    prm = O.OracleParams.from_config(cfg)
+    monkeypatch.setenv("SFM_FUSED", "1")
+    eng = _geo_engine(sc, cfg)
+    try:
+        worst = _geo_oracle_rounds(eng, sc, prm, 4, ((0, n),))
+        print(f"\nfused tick, {n_borders + n_static + 6} polylines on {n} pedestrians vs oracle: conditioned check passed (plain worst |dv'|/|v'| {worst:.3g}: "
+              "hundreds of terms cancel)")
     finally:
         eng.close()
 
