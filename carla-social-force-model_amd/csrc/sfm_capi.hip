@@ -371,8 +371,9 @@ int sfm_create(const SfmParams* params, int device_id, SfmHandle** out) {
         }
     }
     if (exp_env("SFM_FUSED_STAMPS")) {
-        if (hipMalloc(reinterpret_cast<void**>(&h->fused_stamps), sizeof(unsigned long long) * 5 * 4096) != hipSuccess) h->fused_stamps = nullptr;
-        else hipMemset(h->fused_stamps, 0, sizeof(unsigned long long) * 5 * 4096);
+        const size_t words = (size_t)FUSED_STAMP_STRIDE * FUSED_STAMP_WGS;
+        if (hipMalloc(reinterpret_cast<void**>(&h->fused_stamps), sizeof(unsigned long long) * words) != hipSuccess) h->fused_stamps = nullptr;
+        else hipMemset(h->fused_stamps, 0, sizeof(unsigned long long) * words);
     }
     if (exp_env("SFM_GEO_STAMPS")) {
         if (hipMalloc(reinterpret_cast<void**>(&h->geo_stamps), sizeof(unsigned long long) * 4 * 8192) != hipSuccess) h->geo_stamps = nullptr;
@@ -405,10 +406,18 @@ int sfm_destroy(SfmHandle* h) {
         hipFree(h->stamps);
     }
     if (h->fused_stamps && exp_env("SFM_FUSED_STAMPS")) {   // diagnostic: the last fused launch's per-workgroup phase stamps
-        std::vector<unsigned long long> st((size_t)5 * 4096);
+        std::vector<unsigned long long> st((size_t)FUSED_STAMP_STRIDE * FUSED_STAMP_WGS);
         if (hipMemcpy(st.data(), h->fused_stamps, sizeof(unsigned long long) * st.size(), hipMemcpyDeviceToHost) == hipSuccess) {
             FILE* f = fopen(exp_env("SFM_FUSED_STAMPS"), "w");
-            if (f) { for (size_t b = 0; b < 4096; ++b) if (st[5 * b]) fprintf(f, "%zu %llu %llu %llu %llu %llu\n", b, st[5 * b], st[5 * b + 1], st[5 * b + 2], st[5 * b + 3], st[5 * b + 4]); fclose(f); }
+            if (f) {
+                for (size_t b = 0; b < (size_t)FUSED_STAMP_WGS; ++b) {
+                    if (!st[FUSED_STAMP_STRIDE * b]) continue;
+                    fprintf(f, "%zu", b);
+                    for (int k = 0; k < 5 + 32; ++k) fprintf(f, " %llu", st[FUSED_STAMP_STRIDE * b + k]);
+                    fprintf(f, "\n");
+                }
+                fclose(f);
+            }
         }
         hipFree(h->fused_stamps);
     }

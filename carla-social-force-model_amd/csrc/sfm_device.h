@@ -144,6 +144,7 @@ struct SymArgs {
 // four tiles from the previous launch's partial forces (every workgroup that needs a tile recomputes it -- the same arithmetic on
 // the same operands, so all agree bit for bit; the workgroup of the group's diagonal item is the one that stores it), then
 // evaluates its tile pairs of the NEW state.  State, waypoints and partial forces ping-pong between launches.
+constexpr int FUSED_STAMP_STRIDE = 40, FUSED_STAMP_WGS = 4096;   // experiments build: phase stamps of the fused tick (words per workgroup, workgroups kept)
 constexpr int FUSED_GEO_SLICES_MAX = 8;  // geometry workgroups per tile of the fused tick (each leaves one partial sum per pedestrian)
 struct FusedArgs {
     const float2* slab_prev;  // [n_g][N_pad]: slab[r][i] = -A-less force on pedestrian i from the pedestrians of group r, previous state
@@ -160,7 +161,7 @@ struct FusedArgs {
     int geo_slices;           // <= FUSED_GEO_SLICES_MAX
     int n_geo_wg;             // geometry workgroups in front of the grid = n_t * geo_slices (0: the crowd has no such forces)
     int n_pair_wg;            // pair workgroups behind them
-    unsigned long long* stamps;   // experiments build only (SFM_FUSED_STAMPS): per workgroup 5 x s_memrealtime -- entry, column sums in, state in LDS, pairs done, end
+    unsigned long long* stamps;   // experiments build only (SFM_FUSED_STAMPS): per workgroup FUSED_STAMP_STRIDE x s_memrealtime -- entry, column sums in, state in LDS, pairs done, end; per wave: steps done, past the barrier
     int mode;                 // 0: the stored state is the state (nothing to integrate, nothing stored but slab_next): the launch in
                               //    front of a run; 1: integrate by one tick, store, then the pairs of the new state
 };

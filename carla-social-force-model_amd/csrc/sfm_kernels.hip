@@ -19,6 +19,10 @@
 // summation orders: every result is deterministic run to run.
 #include "sfm_device.h"
 
+#ifndef SFM_PK
+#define SFM_PK 1                       // 1: the fused tick's planar systolic step on packed fp32 instructions (A/B, round 4)
+#endif
+
 #include <algorithm>
 #include <cstdlib>
 
@@ -145,6 +149,57 @@ __device__ __forceinline__ void moussaid(const IxConst& c, float dx, float dy, f
     if (Z3) gz = fmaf(e1, tz, gz);
 }
 
+// The wrapped angle between two planar directions, biased (stateutils.py:104-112, forces.py:94,101), from S = m sin, C = m cos of
+// the angle, m > 0 the common scale:  theta = atan2(S, C) - eg Dn.
+// Half-angle form: tan(angle / 2) = S / (m + C); with |C| in the denominator the ratio stays in [-1, 1] for every quadrant and
+//   angle = 2 atan(r) for C >= 0,  sign(S) pi - 2 atan(r) for C < 0,  r = S / (m + |C|),
+// 2 atan(r) = r P(r^2): 8-coefficient minimax fit on [0, 1], relative error 9.9e-8 (below the 2^-22 rad that the angle between two
+// fp32-rounded directions resolves), full relative precision for small angles (head-on encounters, where the force is largest).
+// Round 4: the C < 0 branch is sign arithmetic instead of v_cmp + v_cndmask (issue cost of that pair on MI355X: 16 cycles, as much as
+// 6.7 fmas -- tools/valu_microbench.hip): with s = copysign(1, C) the denominator s (m + |C|) = s m + C hands the ratio the sign that
+// the branch would have given 2 atan(r), and what is left of the branch is the constant k = (1 - s) copysign(pi / 2, S) = 0 or
+// sign(S) pi, added by the fma that finishes the polynomial.  Same values as the branch (C >= 0: p r + 0; C < 0: sign(S) pi - p |r|..)
+// up to the rounding of the denominator; a NaN in m (coincident pair) still comes out as NaN.
+__device__ __forceinline__ float half_angle_theta(float S, float C, float m, float eg, float Dn) {
+#ifndef SFM_ATAN_TERMS
+#define SFM_ATAN_TERMS 8
+#endif
+#if SFM_FIXUP_BRANCH
+    const float r = S * rcp(m + fabsf(C));
+#else
+    const float sc = copysignf(1.0f, C);
+    const float r = S * rcp(fmaf(sc, m, C));
+#endif
+    const float z = r * r;
+#if SFM_ATAN_TERMS == 8
+    float p = -0.0095607885413262813f;
+    p = fmaf(p, z, 0.049113825228842972f);
+    p = fmaf(p, z, -0.11980885478692463f);
+    p = fmaf(p, z, 0.1988547939908939f);
+    p = fmaf(p, z, -0.28058826128196529f);
+    p = fmaf(p, z, 0.39942748114880167f);
+    p = fmaf(p, z, -0.66664186893326649f);
+    p = fmaf(p, z, 1.9999998228145017f);
+#else                                         // 7 coefficients: relative error 6.5e-7 (A/B only)
+    float p = 0.015726754441857338f;
+    p = fmaf(p, z, -0.07402600347995758f);
+    p = fmaf(p, z, 0.16774238646030426f);
+    p = fmaf(p, z, -0.26974382996559143f);
+    p = fmaf(p, z, 0.39762964844703674f);
+    p = fmaf(p, z, -0.6665303111076355f);
+    p = fmaf(p, z, 1.999998688697815f);
+#endif
+#if SFM_FIXUP_BRANCH
+    const float a = p * r;
+    const float ang = (C < 0.0f) ? (copysignf(3.14159265358979324f, S) - a) : a;
+    return fmaf(-eg, Dn, ang);
+#else
+    const float h = copysignf(1.57079632679489662f, S);
+    const float k = fmaf(-eg, Dn, fmaf(-sc, h, h));                    // 0 or sign(S) pi (pi / 2 doubles exactly), minus the bias eps B
+    return fmaf(p, r, k);
+#endif
+}
+
 // The same interaction for the symmetric kernel's planar fast path, arranged for the fewest issued instructions:
 //   (dx,dy) = other - self and d2 = dx^2 + dy^2 come from the caller (it has already tested d2 against the reach);
 //   (wx,wy) = lambda (v_self - v_other) -- both velocities are pre-multiplied by lambda once per tile, so D = w + e is one
@@ -170,19 +225,7 @@ __device__ __forceinline__ bool moussaid_planar(const IxConst& c, float dx, floa
     const float tx = Dx * rD, ty = Dy * rD;
     const float S = fmaf(tx, dy, -(ty * dx));                          // d sin(angle(e) - angle(t))
     const float C = fmaf(tx, dx, ty * dy);                             // d cos
-    const float r = S * rcp(d + fabsf(C));                             // tan(angle / 2) folded into [-1, 1] (see atan2_unit)
-    const float z = r * r;
-    float p = -0.0095607885413262813f;
-    p = fmaf(p, z, 0.049113825228842972f);
-    p = fmaf(p, z, -0.11980885478692463f);
-    p = fmaf(p, z, 0.1988547939908939f);
-    p = fmaf(p, z, -0.28058826128196529f);
-    p = fmaf(p, z, 0.39942748114880167f);
-    p = fmaf(p, z, -0.66664186893326649f);
-    p = fmaf(p, z, 1.9999998228145017f);
-    const float a = p * r;
-    const float ang = (C < 0.0f) ? (copysignf(3.14159265358979324f, S) - a) : a;
-    const float theta = fmaf(-c.eg, Dn, ang);                          // forces.py:101
+    const float theta = half_angle_theta(S, C, d, c.eg, Dn);          // forces.py:94,101
     const float q = Dn * theta;
     const float q2 = q * q;
     const float e1 = ex2(fmaf(q2, c.k1, aL));
@@ -191,6 +234,58 @@ __device__ __forceinline__ bool moussaid_planar(const IxConst& c, float dx, floa
     cx = fmaf(e1, tx, -(g * ty));
     cy = fmaf(e1, ty, g * tx);
     return true;
+}
+
+// The planar body on PACKED fp32 instructions (round 4).  v_pk_add / v_pk_mul / v_pk_fma_f32 issue in 4.3 cycles per wave on MI355X
+// against 2 x 2.4 for the two scalar instructions they replace (tools/valu_microbench.hip), and the interaction is full of x / y pairs:
+// d = p_j - p_i, w = lambda (v_i - v_j), D = d / |d| + w, t = D / |D|, (S, C) = (t x d, t . d), the two exponents, the term (c_x, c_y)
+// and the resident sums.  Ten packed instructions take the place of twenty; swizzles and broadcasts are op_sel bits.  The two
+// products whose halves differ in SIGN -- (S, C) and (-g t_y, g t_x) -- are inline asm: the compiler does not fold a half-negated
+// operand into neg_lo and would build the vector with two more instructions.
+// Same operations on the same operands as moussaid_planar<RAD, false>, hence the same bits.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f bcast(float v) { v2f r; r.x = v; r.y = v; return r; }
+template <bool RAD>
+__device__ __forceinline__ v2f moussaid_planar_pk(const IxConst& c, v2f pj, v2f uj, v2f Ti, v2f Ui, float rsum) {
+    const v2f dd = pj - Ti;                                            // (dx, dy) = other - self
+    const float d2 = fmaf(dd.x, dd.x, dd.y * dd.y);
+    v2f sq, rr;                                                        // (d2, D2) and (1/d, 1/|D|) as register pairs: their product is (d, |D|)
+    sq.x = d2;
+    rr.x = rsq(d2);
+    const v2f Dv = __builtin_elementwise_fma(dd, __builtin_shufflevector(rr, rr, 0, 0), Ui - uj);   // D = e + lambda (v_i - v_j)
+    const float D2 = fmaf(Dv.x, Dv.x, fmaf(Dv.y, Dv.y, TINY));
+    sq.y = D2;
+    rr.y = rsq(D2);
+    const float rD = rr.y;
+    v2f t;                                                             // t = D / |D|  (asm: the compiler would copy 1/|D| out of its pair first.
+    // The s_nop is the wait state a VALU instruction needs before it reads a transcendental's result on gfx950: the compiler puts it
+    // in front of its own instructions and does not look inside an asm statement -- without it t was computed from a stale 1/|D|)
+    asm("s_nop 0\n\tv_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(t) : "v"(Dv), "v"(rr));
+    const v2f A = bcast(t.x) * __builtin_shufflevector(dd, dd, 1, 0);  // (tx dy, tx dx)
+    v2f SC;                                                            // (S, C) = (tx dy - ty dx, tx dx + ty dy)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1] neg_lo:[0,1,0]" : "=v"(SC) : "v"(t), "v"(dd), "v"(A));
+    const v2f dDn = sq * rr;                                           // (d, |D|): neither is needed before here
+    const float theta = half_angle_theta(SC.x, SC.y, dDn.x, c.eg, dDn.y);   // forces.py:94,101
+    float aL, q;
+    if (RAD) {
+        aL = (dDn.x - rsum) * (rD * c.c1);
+        q = dDn.y * theta;
+    } else {
+        v2f X;                                                         // (-d / B log2 e, |D| theta) = (d, |D|) * (c1 / |D|, theta)
+        X.x = rD * c.c1; X.y = theta;
+        const v2f aq = dDn * X;
+        aL = aq.x; q = aq.y;
+    }
+    const float q2 = q * q;
+    v2f kk; kk.x = c.k1; kk.y = c.k2;
+    const v2f arg = __builtin_elementwise_fma(bcast(q2), kk, bcast(aL));
+    const float e1 = ex2(arg.x);
+    const float e2 = ex2(arg.y);
+    const float g = copysignf(e2, theta);
+    v2f gv; gv.x = g;                                                  // (the high half is never read: op_sel picks the low one twice)
+    v2f B;                                                             // (-g ty, g tx)
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[0,0] neg_lo:[0,1]" : "=v"(B) : "v"(gv), "v"(t));
+    return __builtin_elementwise_fma(bcast(e1), t, B);                 // (e1 tx - g ty, e1 ty + g tx)
 }
 
 // The same for a 3-D crowd (round 3; pedestrian_state.py:17-19 keeps 3-component positions and velocities and forces.py:75-117
@@ -216,19 +311,7 @@ __device__ __forceinline__ bool moussaid_spatial(const IxConst& c, float dx, flo
     const float C = fmaf(tx, dx, ty * dy);                             // ... cos
     const float h2 = fmaf(S, S, C * C);
     const float h = h2 * rsq(h2);
-    const float r = S * rcp(h + fabsf(C));                             // tan(angle / 2) folded into [-1, 1] (see atan2_unit)
-    const float z = r * r;
-    float p = -0.0095607885413262813f;
-    p = fmaf(p, z, 0.049113825228842972f);
-    p = fmaf(p, z, -0.11980885478692463f);
-    p = fmaf(p, z, 0.1988547939908939f);
-    p = fmaf(p, z, -0.28058826128196529f);
-    p = fmaf(p, z, 0.39942748114880167f);
-    p = fmaf(p, z, -0.66664186893326649f);
-    p = fmaf(p, z, 1.9999998228145017f);
-    const float a = p * r;
-    const float ang = (C < 0.0f) ? (copysignf(3.14159265358979324f, S) - a) : a;
-    const float theta = fmaf(-c.eg, Dn, ang);                          // forces.py:101
+    const float theta = half_angle_theta(S, C, h, c.eg, Dn);          // forces.py:94,101
     const float q = Dn * theta;
     const float q2 = q * q;
     const float e1 = ex2(fmaf(q2, c.k1, aL));
@@ -1463,7 +1546,7 @@ __device__ __forceinline__ void pair_block(const float4* __restrict__ pk, const 
         sig0 = 16 * wave;
         nsteps = 16;
     }
-    if (sa.debug_steps >= 0) nsteps = sa.debug_steps;
+    if (sa.debug_steps >= 0) nsteps = min(sa.debug_steps, 16);   // (the doubled LDS image holds slots lane + sig0 + s <= 127 only for s < 16)
 
     float fxi = 0.f, fyi = 0.f, fxj = 0.f, fyj = 0.f;
     float fzi = 0.f, fzj = 0.f;                   // 3-D crowds (Z3): the z components (forces.py:112-117 keeps 3-component forces)
@@ -1988,9 +2071,14 @@ struct FusedShared {                             // LDS of one pair-role workgro
 };
 
 #ifdef SFM_EXPERIMENTS
-#define FUSED_STAMP(k) do { if (f.stamps && threadIdx.x == 0) f.stamps[5 * (size_t)blockIdx.x + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+// per workgroup FUSED_STAMP_STRIDE words: [0, 5) thread 0 at entry, column sums in, state in LDS, its steps done, its row stored; then per
+// WAVE [5 + w] the end of its last systolic step and [5 + 16 + w] the end of its share of the row store (round 4: is "steps done ->
+// rows stored" of thread 0 a store tail or the skew between the workgroup's waves?)
+#define FUSED_STAMP(k) do { if (f.stamps && threadIdx.x == 0 && blockIdx.x < FUSED_STAMP_WGS) f.stamps[FUSED_STAMP_STRIDE * (size_t)blockIdx.x + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define FUSED_WAVE_STAMP(k) do { if (f.stamps && (threadIdx.x & 63) == 0 && blockIdx.x < FUSED_STAMP_WGS) f.stamps[FUSED_STAMP_STRIDE * (size_t)blockIdx.x + 5 + (k) * 16 + (threadIdx.x >> 6)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define FUSED_STAMP(k) do { } while (0)
+#define FUSED_WAVE_STAMP(k) do { } while (0)
 #endif
 
 template <bool RAD, int NW, bool Z3, bool GEO>   // NW waves per workgroup (8 or 16): 256 / NW systolic steps each
@@ -2072,12 +2160,15 @@ __global__ __launch_bounds__(NW * WAVE, (NW == 8 && Z3) ? 6 : 8) void sfm_fused_
     //      Every load of the prologue is issued before the first use of any (they come from other XCDs' writes: one round
     //      trip, not several): own state first, then the column sums -- a thread takes two neighbouring pedestrians (16-B
     //      loads) and 1/PARTS of the slab rows.
+    // (everything that decides WHICH rows a wave touches is wave-uniform and kept in SGPRs -- round 4: the twelve upper waves of a
+    //  workgroup branch around the own-row loads and the integration instead of running them with an empty exec mask)
     const bool integrate = f.mode != 0;
-    const int p = tid & (2 * GROUP - 1);         // pedestrian slot (the first 256 threads integrate)
-    const bool lower = tid < 2 * GROUP;
-    const int G = (p < GROUP) ? GX : GY;
+    const int quarter = wave & (2 * GROUP / WAVE - 1);          // which 64 of the workgroup's 256 pedestrian slots this wave maps to
+    const int p = quarter * WAVE + lane;         // pedestrian slot = tid mod 256 (the first 256 threads integrate)
+    const bool lower = wave < 2 * GROUP / WAVE;
+    const int G = (quarter < 2) ? GX : GY;
     const bool present = G < n_g;
-    const int i = G * GROUP + (p & (GROUP - 1)); // < N_pad whenever the group exists (N_pad is a multiple of four tiles)
+    const int i = G * GROUP + (quarter & 1) * WAVE + lane;      // < N_pad whenever the group exists (N_pad is a multiple of four tiles)
     const bool live = present && i < a.N;
     float4 st = make_float4(0.f, 0.f, 0.f, 0.f), o = st;
     float2 stz = make_float2(0.f, 0.f);          // Z3: {z, vz}
@@ -2105,10 +2196,10 @@ __global__ __launch_bounds__(NW * WAVE, (NW == 8 && Z3) ? 6 : 8) void sfm_fused_
     }
     if (tid == 0) sh.any = 0;
     {
-        const int pp = tid & (GROUP - 1);        // pedestrians 2 pp, 2 pp + 1 of the workgroup's 256
-        const int part = uniform(tid >> 7);
-        const int Gq = (2 * pp < GROUP) ? GX : GY;
-        const int i2 = Gq * GROUP + ((2 * pp) & (GROUP - 1));
+        const int pp = (wave & 1) * WAVE + lane; // = tid mod 128: pedestrians 2 pp, 2 pp + 1 of the workgroup's 256
+        const int part = wave >> 1;
+        const int Gq = (wave & 1) ? GY : GX;     // (2 pp < GROUP for the even waves)
+        const int i2 = Gq * GROUP + 2 * lane;
         float4 acc4 = make_float4(0.f, 0.f, 0.f, 0.f);
         float2 accz = make_float2(0.f, 0.f);
         if (integrate && a.en_ped && Gq < n_g && i2 < a.N) {
@@ -2117,8 +2208,17 @@ __global__ __launch_bounds__(NW * WAVE, (NW == 8 && Z3) ? 6 : 8) void sfm_fused_
             const size_t stride4 = (size_t)a.N_pad / 2;
             const int per = (n_g + PARTS - 1) / PARTS;
             const int r1 = min(n_g, (part + 1) * per);
-            if (!Z3) {
-                for (int r0 = part * per; r0 < r1; r0 += 8) {
+            const int r00 = part * per;
+            if (!Z3 && r1 - r00 == 4) {
+                // c2's shape (32 groups over 8 parts): exactly four rows, no predication and no zero fill -- the same association as
+                // the general form below with its absent rows at 0, hence the same bits, in 16 adds instead of 32 + 26 moves (round 4:
+                // every wave of every workgroup runs this before its first systolic step)
+                const float4 v0 = col[(size_t)r00 * stride4], v1 = col[(size_t)(r00 + 1) * stride4];
+                const float4 v2 = col[(size_t)(r00 + 2) * stride4], v3 = col[(size_t)(r00 + 3) * stride4];
+                acc4 = make_float4((v0.x + v1.x) + (v2.x + v3.x), (v0.y + v1.y) + (v2.y + v3.y),
+                                   (v0.z + v1.z) + (v2.z + v3.z), (v0.w + v1.w) + (v2.w + v3.w));
+            } else if (!Z3) {
+                for (int r0 = r00; r0 < r1; r0 += 8) {
                     float4 v[8];
 #pragma unroll
                     for (int k = 0; k < 8; ++k) v[k] = (r0 + k < r1) ? col[(size_t)(r0 + k) * stride4] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -2173,10 +2273,13 @@ __global__ __launch_bounds__(NW * WAVE, (NW == 8 && Z3) ? 6 : 8) void sfm_fused_
         const float z = stz.x, vz = stz.y;
         float wx = o.x, wy = o.y;
         float fax = 0.f, fay = 0.f, faz = 0.f;
+        // (round 4: 1 / |.| by v_rsq_f32 -- 1 ulp -- instead of IEEE sqrt + divide, ~35 instructions less in front of every
+        //  workgroup's first systolic step; the zero vector still normalises to zero, stateutils.py:85-92, and a pedestrian at rest
+        //  with target speed 0 still stays at rest, stateutils.py:20-23)
         if (a.en_acc) {
             const float tx_ = wx - x, ty_ = wy - y;
-            const float nrm = sqrtf(fmaf(tx_, tx_, ty_ * ty_));
-            const float inv = (nrm == 0.0f) ? 1.0f : 1.0f / nrm;
+            const float n2 = fmaf(tx_, tx_, ty_ * ty_);
+            const float inv = (n2 > 0.0f) ? rsq(n2) : 1.0f;
             fax = (ts * (tx_ * inv) - vx) * a.inv_tau;
             fay = (ts * (ty_ * inv) - vy) * a.inv_tau;
             if (Z3) faz = (0.0f - vz) * a.inv_tau;
@@ -2184,9 +2287,8 @@ __global__ __launch_bounds__(NW * WAVE, (NW == 8 && Z3) ? 6 : 8) void sfm_fused_
         const float Fx = (fax + fpx) + geo_f.x, Fy = (fay + fpy) + geo_f.y;   // forces.py order: acceleration, pedestrian, border + obstacles
         const float Fz = faz + fpz;
         float nvx = fmaf(a.dt, Fx, vx), nvy = fmaf(a.dt, Fy, vy), nvz = Z3 ? fmaf(a.dt, Fz, vz) : 0.f;
-        float sp = Z3 ? sqrtf(fmaf(nvx, nvx, fmaf(nvy, nvy, nvz * nvz))) : sqrtf(fmaf(nvx, nvx, nvy * nvy));
-        sp = (sp == 0.0f) ? 1.0f : sp;
-        const float fac = fminf(1.0f, (ts * a.max_speed_factor) / sp);
+        const float s2 = Z3 ? fmaf(nvx, nvx, fmaf(nvy, nvy, nvz * nvz)) : fmaf(nvx, nvx, nvy * nvy);
+        const float fac = (s2 > 0.0f) ? fminf(1.0f, (ts * a.max_speed_factor) * rsq(s2)) : 0.0f;   // (speed 0: the capped velocity is 0 whatever the factor)
         nvx *= fac; nvy *= fac; nvz *= fac;
         float nx = x, ny = y, nz = z;
         if (a.flags & 1u) { nx = fmaf(a.dt, nvx, x); ny = fmaf(a.dt, nvy, y); if (Z3) nz = fmaf(a.dt, nvz, z); }
@@ -2327,6 +2429,9 @@ __global__ __launch_bounds__(NW * WAVE, (NW == 8 && Z3) ? 6 : 8) void sfm_fused_
         float ri = RAD ? radt[0] : 0.f;
         float2 Tz = make_float2(0.f, 0.f);
         if (Z3) Tz = travz[0];
+#if SFM_PK
+        v2f fjv; fjv.x = 0.f; fjv.y = 0.f;       // the resident sums as a register pair (v_pk_add_f32)
+#endif
 #pragma unroll
         for (int s_ = 0; s_ < SPW; ++s_) {
             float4 Tn = T;
@@ -2340,13 +2445,22 @@ __global__ __launch_bounds__(NW * WAVE, (NW == 8 && Z3) ? 6 : 8) void sfm_fused_
                 const float dz = zj - Tz.x;
                 moussaid_spatial<RAD, false>(c, dx, dy, dz, fmaf(dx, dx, fmaf(dy, dy, dz * dz)), T.z - ujx, T.w - ujy, Tz.y - ujz, RAD ? ri + rj : 0.f, cx, cy, cz);
             } else {
+#if SFM_PK
+                v2f pjv, ujv, Tv, Uv;
+                pjv.x = pj.x; pjv.y = pj.y; ujv.x = ujx; ujv.y = ujy; Tv.x = T.x; Tv.y = T.y; Uv.x = T.z; Uv.y = T.w;
+                const v2f cv = moussaid_planar_pk<RAD>(c, pjv, ujv, Tv, Uv, RAD ? ri + rj : 0.f);
+                cx = cv.x; cy = cv.y;
+                if (s_ + 1 < SPW || !tail_one_sided) fjv -= cv;
+#else
                 moussaid_planar<RAD, false>(c, dx, dy, fmaf(dx, dx, dy * dy), T.z - ujx, T.w - ujy, RAD ? ri + rj : 0.f, cx, cy);
+#endif
             }
             // the sums of the pedestrian this lane has just met were in lane + 1 a step ago: rotation and add in one instruction
             fxi = rot_in(fxi) + cx;
             fyi = rot_in(fyi) + cy;
             if (Z3) fzi = rot_in(fzi) + cz;
-            if (s_ + 1 < SPW || !tail_one_sided) { fxj -= cx; fyj -= cy; if (Z3) fzj -= cz; }
+            if (SFM_PK && !Z3) { fxj = fjv.x; fyj = fjv.y; }
+            else if (s_ + 1 < SPW || !tail_one_sided) { fxj -= cx; fyj -= cy; if (Z3) fzj -= cz; }
             T = Tn;
             ri = rin;
             Tz = Tzn;
@@ -2356,11 +2470,13 @@ __global__ __launch_bounds__(NW * WAVE, (NW == 8 && Z3) ? 6 : 8) void sfm_fused_
         }
         i_end_loc = (lane + sig0 + SPW - 1) & (WAVE - 1);
     }
+    FUSED_WAVE_STAMP(0);
     sh.fi[wave][i_end_loc] = make_float2(fxi, fyi);
     sh.fj[wave][lane] = make_float2(fxj, fyj);
     if (Z3) { sh.fiz[Z3 ? wave : 0][i_end_loc] = fzi; sh.fjz[Z3 ? wave : 0][lane] = fzj; }
     FUSED_STAMP(3);
     __syncthreads();
+    FUSED_WAVE_STAMP(1);
     if (!lower || !present) return;
     const int tl = (p >> 6) & 1, l = lane;       // tile of the group, pedestrian of the tile
     // sums of wave w for pedestrian l of its travelling / resident tile, z in the third component

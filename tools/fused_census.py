@@ -29,7 +29,7 @@ eng.synchronize()
 print(eng.engine.kernel_variant())
 eng.close()
 d = np.loadtxt(out, dtype=np.uint64)
-b, t = d[:, 0].astype(int), d[:, 1:].astype(np.int64)
+b, t = d[:, 0].astype(int), d[:, 1:6].astype(np.int64)
 t0 = t[:, 0].min()
 us = (t - t0) * 0.01
 names = ["entry", "column sums in", "state in LDS", "steps done", "rows stored"]
@@ -39,3 +39,21 @@ for k in range(5):
 for k in range(1, 5):
     dt = us[:, k] - us[:, k - 1]
     print(f"  phase -> {names[k]:16s} median {np.median(dt):6.2f}  p10 {np.percentile(dt, 10):6.2f}  p90 {np.percentile(dt, 90):6.2f} us")
+if d.shape[1] >= 6 + 32:
+    # per WAVE: end of its last systolic step, and the moment it is past the barrier that follows (round 4)
+    w = (d[:, 6:6 + 32].astype(np.int64) - t0) * 0.01
+    nw = int((d[0, 6:6 + 16] != 0).sum())
+    done, past = w[:, :nw], w[:, 16:16 + nw]
+    first, last = done.min(axis=1), done.max(axis=1)
+    def line(name, v):
+        print(f"  {name:58s} median {np.median(v):6.2f}  p10 {np.percentile(v, 10):6.2f}  p90 {np.percentile(v, 90):6.2f}  max {v.max():6.2f} us")
+    print(f"per wave ({nw} waves per workgroup):")
+    line("first wave of the workgroup done with its steps at", first)
+    line("last wave of the workgroup done with its steps at", last)
+    line("skew inside a workgroup (last - first wave done)", last - first)
+    line("thread 0 'steps done' -> LAST wave of its workgroup done", last - us[:, 3])
+    line("last wave done -> all past the barrier", past.max(axis=1) - last)
+    line("last wave done -> thread 0's row stored (combine + store)", us[:, 4] - last)
+    order = np.argsort(np.argsort(done, axis=1), axis=1)            # rank of each wave's finishing time inside its workgroup
+    print("  mean finishing rank of wave w (0 = first):", " ".join(f"{order[:, k].mean():.1f}" for k in range(nw)))
+    print(f"  the launch's last systolic step ends at {last.max():.2f} us; last row stored at {us[:, 4].max():.2f} us")
