@@ -144,7 +144,8 @@ struct SfmHandle {
     bool perm_stale = false;
     float r_max = 0.f;
     bool used_sym = false;
-    // fused tick (sfm_fused_tick_kernel): one launch per tick inside sfm_run for a whole planar crowd without border / obstacle forces
+    // fused tick (sfm_fused_tick_kernel): one launch per tick inside sfm_run for a whole crowd while the list cutoff is off (default: N <= 4096) --
+    // planar or 3-D, with or without border / obstacle forces and device-side vehicles
     float2* fslab = nullptr;               // [2][n_g][N_pad] partial forces, ping-pong across launches
     size_t fslab_cap = 0;
     float* fslabz = nullptr;               // 3-D crowds: their z components
@@ -155,7 +156,7 @@ struct SfmHandle {
     int list_merge_mode = -1;              // SFM_LIST_MERGE=0: the flat tile-pair list always gets a launch of its own (A/B, tests)
     int fused_mode = -1;                   // SFM_FUSED=0: always the two-kernel tick (A/B, tests)
     int fused_waves = 16, fused_blocked = 1;   // SFM_FUSED_WAVES=8 / SFM_FUSED_BLOCKED=0: its A/B variants (tests)
-    float2* fgeo = nullptr;                // [2][4][N_pad] border + obstacle forces of the fused tick, one float2 per pedestrian and slice, ping-pong
+    float2* fgeo = nullptr;                // [2][FUSED_GEO_SLICES_MAX][N_pad] border + obstacle forces of the fused tick, one float2 per pedestrian and slice, ping-pong
     size_t fgeo_cap = 0;
     float4* dyn_ctr_alt = nullptr;         // device-side vehicles in the fused tick: the NEXT tick's centres / rings (ping-pong with dynamics.ctr / .pts)
     float2* dyn_pts_alt = nullptr;
@@ -1449,6 +1450,13 @@ int sfm_profile_dominant_kernel(SfmHandle* h, int reps, float* avg_us) {
             HIP_TRY(h, hipMemcpyAsync(ctr_keep, h->dynamics.ctr, sizeof(float4) * (size_t)h->dynamics.K, hipMemcpyDeviceToDevice, h->stream));
             HIP_TRY(h, hipMemcpyAsync(pts_keep, h->dynamics.pts, sizeof(float2) * (size_t)h->dynamics.P, hipMemcpyDeviceToDevice, h->stream));
         }
+        // a 3-D crowd's {z, vz} rows are integrated by these launches as well (round-3 advisor finding: they were left reps + 1 ticks ahead)
+        float2* zv_keep = nullptr;
+        struct KeepZ { float2*& a; ~KeepZ() { if (a) hipFree(a); } } keepz{zv_keep};
+        if (h->z3) {
+            HIP_TRY(h, dev_realloc(zv_keep, np_));
+            HIP_TRY(h, hipMemcpyAsync(zv_keep, h->zv[h->cur], sizeof(float2) * np_, hipMemcpyDeviceToDevice, h->stream));
+        }
         HIP_TRY(h, hipMemcpyAsync(pk_keep, h->pk[h->cur], sizeof(float4) * np_, hipMemcpyDeviceToDevice, h->stream));
         HIP_TRY(h, hipMemcpyAsync(own_keep, h->own, sizeof(float4) * np_, hipMemcpyDeviceToDevice, h->stream));
         HIP_TRY(h, hipMemcpyAsync(draws_keep, h->draws, sizeof(uint32_t) * np_, hipMemcpyDeviceToDevice, h->stream));
@@ -1463,6 +1471,7 @@ int sfm_profile_dominant_kernel(SfmHandle* h, int reps, float* avg_us) {
         if (rc) return rc;
         HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
         HIP_TRY(h, hipMemcpyAsync(h->pk[h->cur], pk_keep, sizeof(float4) * np_, hipMemcpyDeviceToDevice, h->stream));
+        if (h->z3) HIP_TRY(h, hipMemcpyAsync(h->zv[h->cur], zv_keep, sizeof(float2) * np_, hipMemcpyDeviceToDevice, h->stream));
         HIP_TRY(h, hipMemcpyAsync(h->own, own_keep, sizeof(float4) * np_, hipMemcpyDeviceToDevice, h->stream));
         HIP_TRY(h, hipMemcpyAsync(h->draws, draws_keep, sizeof(uint32_t) * np_, hipMemcpyDeviceToDevice, h->stream));
         if (veh) {

@@ -245,10 +245,13 @@ __device__ __forceinline__ bool moussaid_planar(const IxConst& c, float dx, floa
 // Same operations on the same operands as moussaid_planar<RAD, false>, hence the same bits.
 typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f bcast(float v) { v2f r; r.x = v; r.y = v; return r; }
-template <bool RAD>
-__device__ __forceinline__ v2f moussaid_planar_pk(const IxConst& c, v2f pj, v2f uj, v2f Ti, v2f Ui, float rsum) {
+// CUT (the list-cutoff workloads' pair kernel): the two wave-uniform tests of moussaid_planar<RAD, true> and its caller -- all 64 pairs
+// beyond reach2, all 64 exponents below -41 -- return false with the term not evaluated.
+template <bool RAD, bool CUT>
+__device__ __forceinline__ bool moussaid_planar_pk(const IxConst& c, v2f pj, v2f uj, v2f Ti, v2f Ui, float rsum, float reach2, v2f& term) {
     const v2f dd = pj - Ti;                                            // (dx, dy) = other - self
     const float d2 = fmaf(dd.x, dd.x, dd.y * dd.y);
+    if (CUT && !__any(!(d2 > reach2))) return false;
     v2f sq, rr;                                                        // (d2, D2) and (1/d, 1/|D|) as register pairs: their product is (d, |D|)
     sq.x = d2;
     rr.x = rsq(d2);
@@ -257,6 +260,12 @@ __device__ __forceinline__ v2f moussaid_planar_pk(const IxConst& c, v2f pj, v2f 
     sq.y = D2;
     rr.y = rsq(D2);
     const float rD = rr.y;
+    float aL = 0.f;
+    if (CUT) {                                                         // the exponent is needed now: -d / B log2 e
+        const float d_ = d2 * rr.x;
+        aL = (RAD ? d_ - rsum : d_) * (rD * c.c1);
+        if (!__any(!(aL <= -41.0f))) return false;
+    }
     v2f t;                                                             // t = D / |D|  (asm: the compiler would copy 1/|D| out of its pair first.
     // The s_nop is the wait state a VALU instruction needs before it reads a transcendental's result on gfx950: the compiler puts it
     // in front of its own instructions and does not look inside an asm statement -- without it t was computed from a stale 1/|D|)
@@ -266,8 +275,10 @@ __device__ __forceinline__ v2f moussaid_planar_pk(const IxConst& c, v2f pj, v2f 
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1] neg_lo:[0,1,0]" : "=v"(SC) : "v"(t), "v"(dd), "v"(A));
     const v2f dDn = sq * rr;                                           // (d, |D|): neither is needed before here
     const float theta = half_angle_theta(SC.x, SC.y, dDn.x, c.eg, dDn.y);   // forces.py:94,101
-    float aL, q;
-    if (RAD) {
+    float q;
+    if (CUT) {
+        q = dDn.y * theta;
+    } else if (RAD) {
         aL = (dDn.x - rsum) * (rD * c.c1);
         q = dDn.y * theta;
     } else {
@@ -285,7 +296,8 @@ __device__ __forceinline__ v2f moussaid_planar_pk(const IxConst& c, v2f pj, v2f 
     v2f gv; gv.x = g;                                                  // (the high half is never read: op_sel picks the low one twice)
     v2f B;                                                             // (-g ty, g tx)
     asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[0,0] neg_lo:[0,1]" : "=v"(B) : "v"(gv), "v"(t));
-    return __builtin_elementwise_fma(bcast(e1), t, B);                 // (e1 tx - g ty, e1 ty + g tx)
+    term = __builtin_elementwise_fma(bcast(e1), t, B);                 // (e1 tx - g ty, e1 ty + g tx)
+    return true;
 }
 
 // The same for a 3-D crowd (round 3; pedestrian_state.py:17-19 keeps 3-component positions and velocities and forces.py:75-117
@@ -1586,6 +1598,7 @@ __device__ __forceinline__ void pair_block(const float4* __restrict__ pk, const 
         float ri = RAD ? radt[0] : 0.f;
         float2 Tz = make_float2(0.f, 0.f);
         if (Z3) Tz = travz[0];
+        v2f fjv; fjv.x = 0.f; fjv.y = 0.f;       // planar: the resident sums as a register pair (v_pk_add_f32)
         // (steps are not interleaved: measured on MI355X, round 2 -- eight waves per SIMD already hide a step's dependent chain;
         //  unrolled by four only so that the slot offsets are immediates of the LDS reads)
         auto step = [&](int s_) __attribute__((always_inline)) {
@@ -1595,10 +1608,23 @@ __device__ __forceinline__ void pair_block(const float4* __restrict__ pk, const 
             float2 Tzn = make_float2(0.f, 0.f);
             if (Z3) Tzn = travz[s_ + 1];
             __builtin_amdgcn_sched_barrier(0);
+            bool done = false;
+#if SFM_PK
+            if (!Z3) {                            // planar crowds: the step on packed fp32 instructions (round 4)
+                v2f pjv, ujv, Tv, Uv, cv;
+                pjv.x = pj.x; pjv.y = pj.y; ujv.x = ujx; ujv.y = ujy; Tv.x = T.x; Tv.y = T.y; Uv.x = T.z; Uv.y = T.w;
+                if (moussaid_planar_pk<RAD, CUT>(c, pjv, ujv, Tv, Uv, RAD ? ri + rj : 0.f, reach2, cv)) {
+                    fxi = rot_in(fxi) + cv.x;
+                    fyi = rot_in(fyi) + cv.y;
+                    if (s_ < one_sided_from) fjv -= cv;
+                    done = true;
+                }
+            } else
+#endif
+            {
             const float dx = pj.x - T.x, dy = pj.y - T.y;
             const float dz = Z3 ? zj - Tz.x : 0.f;
             const float d2 = Z3 ? fmaf(dx, dx, fmaf(dy, dy, dz * dz)) : fmaf(dx, dx, dy * dy);
-            bool done = false;
             if (!CUT || __any(!(d2 > reach2))) {
                 float cx, cy, cz = 0.f;
                 const bool kept = Z3 ? moussaid_spatial<RAD, CUT>(c, dx, dy, dz, d2, T.z - ujx, T.w - ujy, Tz.y - ujz, RAD ? ri + rj : 0.f, cx, cy, cz)
@@ -1611,6 +1637,7 @@ __device__ __forceinline__ void pair_block(const float4* __restrict__ pk, const 
                     if (s_ < one_sided_from) { fxj -= cx; fyj -= cy; if (Z3) fzj -= cz; }
                     done = true;
                 }
+            }
             }
             if (CUT && !done) { fxi = rot_in(fxi); fyi = rot_in(fyi); if (Z3) fzi = rot_in(fzi); }
             T = Tn;
@@ -1626,6 +1653,7 @@ __device__ __forceinline__ void pair_block(const float4* __restrict__ pk, const 
             for (int s_ = 0; s_ < nsteps; ++s_) step(s_);
         }
         i_end_loc = (lane + sig0 + nsteps - 1) & (WAVE - 1);
+        if (SFM_PK && !Z3) { fxj = fjv.x; fyj = fjv.y; }
       }
     }
     sh.fi[wave][i_end_loc] = make_float2(fxi, fyi);
@@ -2448,7 +2476,8 @@ __global__ __launch_bounds__(NW * WAVE, (NW == 8 && Z3) ? 6 : 8) void sfm_fused_
 #if SFM_PK
                 v2f pjv, ujv, Tv, Uv;
                 pjv.x = pj.x; pjv.y = pj.y; ujv.x = ujx; ujv.y = ujy; Tv.x = T.x; Tv.y = T.y; Uv.x = T.z; Uv.y = T.w;
-                const v2f cv = moussaid_planar_pk<RAD>(c, pjv, ujv, Tv, Uv, RAD ? ri + rj : 0.f);
+                v2f cv;
+                moussaid_planar_pk<RAD, false>(c, pjv, ujv, Tv, Uv, RAD ? ri + rj : 0.f, 0.f, cv);
                 cx = cv.x; cy = cv.y;
                 if (s_ + 1 < SPW || !tail_one_sided) fjv -= cv;
 #else

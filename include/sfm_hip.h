@@ -163,7 +163,8 @@ int sfm_download_modes(SfmHandle* h, uint8_t* mode, float* target_speed, int32_t
 int sfm_tick(SfmHandle* h, uint32_t flags);
 /* `ticks` ticks back to back without host intervention (device-resident loop for benchmarks and the
  * CARLA-free harness; the loop of run_simulation.py:212-221 without the simulator); flags as above,
- * SFM_TICK_INTEGRATE is implied.  A whole crowd of up to 4096 pedestrians -- planar or 3-D, with or
+ * SFM_TICK_INTEGRATE is implied.  A whole crowd while the tile-pair list cutoff is off (default: up to 4096
+ * pedestrians; SFM_CUTOFF=0: any size) -- planar or 3-D, with or
  * without border / obstacle forces and vehicles that move on the device -- takes ONE launch per tick here
  * (sfm_fused_tick_kernel) whatever `ticks` is, so what a run computes does not depend on how
  * the caller cuts it into calls; consecutive sfm_run / sfm_tick calls with no other call on the handle in

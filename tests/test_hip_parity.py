@@ -1258,3 +1258,33 @@ def test_straight_border_shortcut_equals_the_full_scan(n, monkeypatch):
     assert np.abs(per["border_force"]).max() > 0.1
     assert np.array_equal(got["shortcut"], got["scan"])
     P.check_force("border_force", got["shortcut"], per["border_force"], diag["border_force"][1], diag["border_force"][0])
+
+
+@pytest.mark.parametrize("z_spread", [0.0, 1.5])
+def test_profiling_the_dominant_kernel_leaves_the_state_alone(z_spread):
+    """sfm_profile_dominant_kernel after a fused run times real integrating launches on a saved state and puts the state back
+    (bench.py's roofline leg calls it in the middle of a run).  Round-3 advisor finding: a 3-D crowd's {z, vz} rows were not
+    saved, so they came back reps + 1 ticks ahead of x, y, vx, vy.  State, waypoints and draw counters before == after, bit for
+    bit, planar and 3-D, and the run carries on to the same state as a run that was never profiled."""
+    n = 700
+    sc = _geo_scenario(n, 8800, z_spread)
+    cfg = default_sfm_config(scenarios.ALL_FORCES)
+    out = {}
+    for tag in ("profiled", "plain"):
+        eng = _geo_engine(sc, cfg)
+        try:
+            eng.run(5, redraw=True)
+            assert "fused" in eng.kernel_variant(), eng.kernel_variant()
+            before = eng.state() + (eng.draw_counts(),) + tuple(np.concatenate([c.ravel(), r.ravel()]) for c, r in eng.dynamic_obstacles())
+            if tag == "profiled":
+                us = eng.profile_dominant_kernel(7)
+                assert us > 0.0
+                after = eng.state() + (eng.draw_counts(),) + tuple(np.concatenate([c.ravel(), r.ravel()]) for c, r in eng.dynamic_obstacles())
+                for a, b in zip(before, after):
+                    assert np.array_equal(a, b, equal_nan=True)
+            eng.run(5, redraw=True)
+            out[tag] = eng.state() + (eng.draw_counts(),)
+        finally:
+            eng.close()
+    for a, b in zip(out["profiled"], out["plain"]):
+        assert np.array_equal(a, b, equal_nan=True)
