@@ -14,7 +14,8 @@ import numpy as np
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SFM_LIB_PATH") or os.path.join(PKG_DIR, "libsfm_hip.so")   # (the override is for A/B builds of the kernels)
-ABI_VERSION = 3
+ABI_VERSION = 4
+SINCE = {"sfm_step_packed": 4}      # entry points younger than ABI 3: an OLDER build named by SFM_LIB_PATH (A/B of builds) may lack them
 
 FORCE_NAMES = ("acceleration_force", "pedestrian_force", "border_force",
                "static_obstacle_force", "dynamic_obstacle_force")
@@ -67,6 +68,7 @@ SYMBOLS = {
     "sfm_run": (C.c_int, [_H, C.c_int, C.c_uint32]),
     "sfm_run_recorded": (C.c_int, [_H, C.c_int, C.c_uint32, C.c_int, _F, C.c_int, C.POINTER(C.c_int)]),
     "sfm_download_velocities": (C.c_int, [_H, _F, _F, _F]),
+    "sfm_step_packed": (C.c_int, [_H, C.c_int, _F, _F, C.c_uint32, _F]),
     "sfm_download_state": (C.c_int, [_H, _F, _F, _F, _F, _F, _F, _F, _F]),
     "sfm_download_forces": (C.c_int, [_H, C.c_int, _F, _F, _F]),
     "sfm_get_arrived": (C.c_int, [_H, C.c_float, _U8]),
@@ -109,16 +111,23 @@ def load():
         lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
     except OSError as e:
         raise SfmLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    try:
+        lib.sfm_abi_version.restype = C.c_int
+        v = lib.sfm_abi_version()
+    except AttributeError as e:
+        raise SfmLibraryError(f"{LIB_PATH} does not export sfm_abi_version (stale build?)") from e
+    # the in-tree build must be THE version; another build named by SFM_LIB_PATH (tools/ab_lib.sh) may be older, additions-only ABI
+    if v != ABI_VERSION and not (os.environ.get("SFM_LIB_PATH") and 3 <= v < ABI_VERSION):
+        raise SfmLibraryError(f"libsfm_hip ABI {v} != expected {ABI_VERSION}: rebuild the extension")
     for name, (res, args) in SYMBOLS.items():
+        if SINCE.get(name, 0) > v:
+            continue
         try:
             fn = getattr(lib, name)
         except AttributeError as e:
             raise SfmLibraryError(f"{LIB_PATH} does not export {name} (stale build?)") from e
         fn.restype = res
         fn.argtypes = args
-    v = lib.sfm_abi_version()
-    if v != ABI_VERSION:
-        raise SfmLibraryError(f"libsfm_hip ABI {v} != expected {ABI_VERSION}: rebuild the extension")
     _lib = lib
     return lib
 

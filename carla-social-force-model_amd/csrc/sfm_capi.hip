@@ -161,6 +161,8 @@ struct SfmHandle {
     float4* dyn_ctr_alt = nullptr;         // device-side vehicles in the fused tick: the NEXT tick's centres / rings (ping-pong with dynamics.ctr / .pts)
     float2* dyn_pts_alt = nullptr;
     size_t dyn_ctr_alt_cap = 0, dyn_pts_alt_cap = 0;
+    std::vector<float> step_cols;          // sfm_step_packed: the packed block taken apart into the columns sfm_upload_state consumes
+    std::vector<uint8_t> step_mask;
     unsigned long long* fused_stamps = nullptr;   // experiments build, SFM_FUSED_STAMPS=<file>: phase stamps of the last fused launch
     int fused_geo_slices = 0;              // SFM_FUSED_GEO_SLICES: A/B
     int fused_geo_mode = -1;               // SFM_FUSED_GEO=0: crowds with border / obstacle forces keep the two-launch tick (A/B, tests)
@@ -365,8 +367,9 @@ int sfm_create(const SfmParams* params, int device_id, SfmHandle** out) {
     ov = getenv("SFM_RESORT_EVERY");
     if (ov) h->resort_every = atoi(ov);
     if (exp_env("SFM_STAMPS")) {
-        if (hipMalloc(reinterpret_cast<void**>(&h->stamps), sizeof(unsigned long long) * 3 * 8192) != hipSuccess) h->stamps = nullptr;
+        if (hipMalloc(reinterpret_cast<void**>(&h->stamps), sizeof(unsigned long long) * 3 * PAIR_STAMP_WGS) != hipSuccess) h->stamps = nullptr;
         else {
+            hipMemset(h->stamps, 0, sizeof(unsigned long long) * 3 * PAIR_STAMP_WGS);
             FILE* f = fopen(exp_env("SFM_STAMPS"), "w");   // the address is read back by the diagnostic script through the dump below
             if (f) fclose(f);
         }
@@ -399,10 +402,10 @@ int sfm_destroy(SfmHandle* h) {
     hipSetDevice(h->device);
     hipStreamSynchronize(h->stream);
     if (h->stamps && exp_env("SFM_STAMPS")) {       // diagnostic: dump the last launch's per-workgroup stamps
-        std::vector<unsigned long long> st(3 * 8192);
+        std::vector<unsigned long long> st((size_t)3 * PAIR_STAMP_WGS);
         if (hipMemcpy(st.data(), h->stamps, sizeof(unsigned long long) * st.size(), hipMemcpyDeviceToHost) == hipSuccess) {
             FILE* f = fopen(exp_env("SFM_STAMPS"), "w");
-            if (f) { for (size_t b = 0; b < 8192; ++b) fprintf(f, "%llu %llu %llu\n", st[3 * b], st[3 * b + 1], st[3 * b + 2]); fclose(f); }
+            if (f) { for (size_t b = 0; b < (size_t)PAIR_STAMP_WGS; ++b) if (st[3 * b + 1]) fprintf(f, "%llu %llu %llu\n", st[3 * b], st[3 * b + 1], st[3 * b + 2]); fclose(f); }
         }
         hipFree(h->stamps);
     }
@@ -1179,7 +1182,8 @@ static int merged_geo_slices(int tiles, int slices) {
     static const int ov = exp_env("SFM_PG_SLICES") ? atoi(exp_env("SFM_PG_SLICES")) : 0;      // A/B only
     (void)slices;
     if (ov > 0) return std::min(GEO_SLICES_MAX, ov);
-    return tiles >= 1024 ? 1 : tiles >= 64 ? 4 : tiles > 32 ? 8 : 16;
+    // (a shard of a large crowd -- 512 own tiles of 4096: c5, one rank of 8 -- 150.3 us per tick at 4, 146.3 at 2, tools/shard_rank_time.py)
+    return tiles >= 1024 ? 1 : tiles >= 512 ? 2 : tiles >= 64 ? 4 : tiles > 32 ? 8 : 16;
 }
 
 static int run_ticks(SfmHandle* h, int ticks, uint32_t flags, int phase = PHASE_FULL, bool device_run = false) {
@@ -1368,7 +1372,7 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags, int phase = PHASE_
             }
             // a shard's epilogue leaves the list counter(s) at zero as well (its boxes cannot be carried -- the other ranks' rows
             // arrive in between -- but the memset can go)
-            const bool shard_zero = !whole && list_cut && (flags & SFM_TICK_INTEGRATE) && h->carry_mode != 0;
+            const bool shard_zero = !whole && list_cut && h->carry_mode != 0;
             if (sa.work && !list_in_geo) {
                 HIP_TRY(h, launch_sym_list(a, sa, h->stream, finishing ? LIST_REMOTE : LIST_ALL, (carried || !whole) && h->count_zeroed));
                 ++launches;
@@ -1604,6 +1608,51 @@ int sfm_download_velocities(SfmHandle* h, float* vx, float* vy, float* vz) {
         vx[i] = pk[s_ - h->i_begin].z;
         vy[i] = pk[s_ - h->i_begin].w;
         if (vz) vz[i] = h->z3 ? zv[s_ - h->i_begin].y : 0.f;
+    }
+    return SFM_OK;
+}
+
+// One host-in-the-loop tick in ONE call (round 4): what the drop-in facade does per PedestrianSimulation.tick
+// (pedestrian_simulation.py:57-83 as run_simulation.py:102-114 drives it) -- numeric columns up, one tick, v' down -- without three
+// trips through the binding and nine column conversions on the caller's side.
+//   rows  [N][9]  {x, y, vx, vy, waypoint x, waypoint y, target_speed, radius, border-force-off flag (0 / 1)}
+//   zvz   [N][2]  {z, vz}, or NULL for a planar crowd
+//   v_out [N][3]  {vx', vy', vz'} (vz' = 0 for a planar crowd)
+// The block is taken apart into the arrays sfm_upload_state consumes (crowds that go through here are host-in-the-loop crowds of a
+// few thousand pedestrians at most: a pass over 36 N bytes), so everything an upload settles -- packing, padding rows, capacities --
+// is settled by the same code; v' comes back through a pinned block.
+int sfm_step_packed(SfmHandle* h, int N, const float* rows, const float* zvz, uint32_t flags, float* v_out) {
+    if (!h) return SFM_ERR_INVALID;
+    if (N < 0 || (N > 0 && (!rows || !v_out))) { int rc = bind(h); return rc ? rc : fail(h, SFM_ERR_INVALID, "N < 0, or rows / v_out is NULL"); }
+    std::vector<float>& c = h->step_cols;
+    const size_t n = (size_t)N;
+    c.resize(10 * n + 1);
+    float *x = c.data(), *y = x + n, *vx = y + n, *vy = vx + n, *wx = vy + n, *wy = wx + n, *ts = wy + n, *rr = ts + n, *z = rr + n, *vz = z + n;
+    h->step_mask.resize(n + 1);
+    uint8_t* cm = h->step_mask.data();
+    for (size_t i = 0; i < n; ++i) {
+        const float* r = rows + 9 * i;
+        x[i] = r[0]; y[i] = r[1]; vx[i] = r[2]; vy[i] = r[3]; wx[i] = r[4]; wy[i] = r[5]; ts[i] = r[6]; rr[i] = r[7];
+        cm[i] = r[8] != 0.0f ? 1 : 0;
+        if (zvz) { z[i] = zvz[2 * i]; vz[i] = zvz[2 * i + 1]; }
+    }
+    int rc = sfm_upload_state(h, N, x, y, zvz ? z : nullptr, vx, vy, zvz ? vz : nullptr, wx, wy, ts, rr, cm);
+    if (rc) return rc;
+    rc = run_ticks(h, 1, flags);
+    if (rc || N == 0) return rc;
+    rc = sync_perm(h);
+    if (rc) return rc;
+    // v' of the rows [i_begin, i_end) = all of them (the upload reset the shard), through the pinned block of the upload
+    const size_t need = sizeof(float4) * n + (h->z3 ? sizeof(float2) * n : 0);
+    if (need > h->up_stage_cap) return fail(h, SFM_ERR_STATE, "staging block smaller than the state it has just carried");
+    float4* pk = reinterpret_cast<float4*>(h->up_stage);
+    float2* zv = reinterpret_cast<float2*>(h->up_stage + sizeof(float4) * n);
+    HIP_TRY(h, hipMemcpyAsync(pk, h->pk[h->cur], sizeof(float4) * n, hipMemcpyDeviceToHost, h->stream));
+    if (h->z3) HIP_TRY(h, hipMemcpyAsync(zv, h->zv[h->cur], sizeof(float2) * n, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    for (size_t s_ = 0; s_ < n; ++s_) {
+        const size_t i = h->perm[s_];
+        v_out[3 * i] = pk[s_].z; v_out[3 * i + 1] = pk[s_].w; v_out[3 * i + 2] = h->z3 ? zv[s_].y : 0.f;
     }
     return SFM_OK;
 }

@@ -144,6 +144,7 @@ struct SymArgs {
 // four tiles from the previous launch's partial forces (every workgroup that needs a tile recomputes it -- the same arithmetic on
 // the same operands, so all agree bit for bit; the workgroup of the group's diagonal item is the one that stores it), then
 // evaluates its tile pairs of the NEW state.  State, waypoints and partial forces ping-pong between launches.
+constexpr int PAIR_STAMP_WGS = 65536;   // experiments build: workgroups of the symmetric pair kernel whose {start, end, HW id} stamps are kept
 constexpr int FUSED_STAMP_STRIDE = 40, FUSED_STAMP_WGS = 4096;   // experiments build: phase stamps of the fused tick (words per workgroup, workgroups kept)
 constexpr int FUSED_GEO_SLICES_MAX = 8;  // geometry workgroups per tile of the fused tick (each leaves one partial sum per pedestrian)
 struct FusedArgs {

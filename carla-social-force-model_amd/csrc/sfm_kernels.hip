@@ -580,8 +580,13 @@ __device__ __forceinline__ int geo_find(const TickArgs& a, const GeoLane& me, co
         //  first of the tile's two workgroups: scan 7.2 us there against 2.8 us in the other)
         const int gw = (gwave + n_gwaves - dealt % n_gwaves) % n_gwaves;
         dealt += g.K;
+        // Round 4: with many polylines per wave they are dealt in runs of up to 8 neighbours instead of one by one.  A lane's records
+        // (16 B centre, 2 x 16 B chord, two offsets) then share cache lines with its neighbours' -- dealt singly, at a stride of
+        // n_gwaves records, every one of a trip's five loads touched 64 lines -- while the scan work still spreads over the waves
+        // (>= 8 runs per wave before runs are used at all; small crowds keep the one-by-one deal).
+        const int run_log = g.K >= 64 * n_gwaves ? 3 : g.K >= 32 * n_gwaves ? 2 : g.K >= 16 * n_gwaves ? 1 : 0;   // (no division: this is on every geometry workgroup's chain)
         for (int base = 0; base < g.K; base += WAVE * n_gwaves) {
-            const int k = base + lane * n_gwaves + gw;
+            const int k = base + ((((lane >> run_log) * n_gwaves + gw) << run_log) | (lane & ((1 << run_log) - 1)));
             bool near = false;
             float4 c = make_float4(0.f, 0.f, 0.f, 0.f), s0 = c, s1 = c;
             int o0 = 0, o1 = 0;
@@ -1330,13 +1335,24 @@ __global__ __launch_bounds__(TSB_WAVES * WAVE) void sfm_tile_strip_bounds_kernel
     const int wave = uniform((int)(threadIdx.x >> 6));
     const float inf = __builtin_inff();
     float sx0 = inf, sy0 = inf, sx1 = -inf, sy1 = -inf, sv = 0.0f;            // this wave's share of the strip (uniform)
-    for (int q = wave; q < tps; q += TSB_WAVES) {
+    // (round 4: four tiles' rows in flight per wave -- a strip of 64 tiles used to be four dependent round trips per wave, and on a
+    //  shard of a large crowd this launch is a fixed cost of every tick)
+    constexpr int TSB_AHEAD = 4;
+  for (int q0 = wave; q0 < tps; q0 += TSB_WAVES * TSB_AHEAD) {
+    float4 pre[TSB_AHEAD];
+#pragma unroll
+    for (int u = 0; u < TSB_AHEAD; ++u) {
+        const int t = s * tps + q0 + u * TSB_WAVES, i = t * WAVE + lane;
+        pre[u] = (q0 + u * TSB_WAVES < tps && t < n_t && i < N) ? pk[i] : make_float4(3.0e15f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < TSB_AHEAD; ++u) {
+        const int q = q0 + u * TSB_WAVES;
         const int t = s * tps + q;
-        if (t >= n_t) break;
-        const int i = t * WAVE + lane;
+        if (q >= tps || t >= n_t) break;
         float x0 = inf, y0 = inf, x1 = -inf, y1 = -inf, v = 0.0f;
-        if (i < N) {
-            const float4 p = pk[i];
+        {
+            const float4 p = pre[u];
             if (fabsf(p.x) < 1.0e14f) {
                 x0 = x1 = p.x; y0 = y1 = p.y;
                 v = sqrtf(fmaf(p.z, p.z, p.w * p.w)) * 1.000001f;
@@ -1351,6 +1367,7 @@ __global__ __launch_bounds__(TSB_WAVES * WAVE) void sfm_tile_strip_bounds_kernel
         if (lane == 0) { box[t] = make_float4(x0, y0, x1, y1); vmax[t] = v; }
         sx0 = fminf(sx0, x0); sy0 = fminf(sy0, y0); sx1 = fmaxf(sx1, x1); sy1 = fmaxf(sy1, y1); sv = fmaxf(sv, v);
     }
+  }
     if (lane == 0) { s_part[wave][0] = sx0; s_part[wave][1] = sy0; s_part[wave][2] = sx1; s_part[wave][3] = sy1; s_part[wave][4] = sv; }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -1687,7 +1704,7 @@ __device__ __forceinline__ void pair_block(const float4* __restrict__ pk, const 
     }
     if (sa.work) __syncthreads();                 // LDS is reused by the next item
   }
-    if (sa.stamps && tid == 0) {
+    if (sa.stamps && tid == 0 && (size_t)bid_y * grid_x + bid_x < (size_t)PAIR_STAMP_WGS) {
         const size_t b = (size_t)bid_y * grid_x + bid_x;
         unsigned hw;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
@@ -2660,6 +2677,12 @@ static void launch_sym_pair_geo_t(dim3 grid, const TickArgs& a, const SymArgs& s
     else hipLaunchKernelGGL((sfm_pair_geo_kernel<RAD, CUT, false>), grid, dim3(BLOCK), 0, st, a, sa, tiles, stride);
 }
 
+// List mode: the grid is a few times what fits at once, each workgroup a contiguous run of the list.  The list holds the items of the
+// OWN tiles (a shard's list is an eighth of the whole crowd's: with the whole crowd's 16 rounds its workgroups got 0.8 items each and
+// a third of the launch was workgroups that found nothing -- c5, one rank of 8: 151.7 us per tick at 16 rounds, 148.2 at 8,
+// tools/shard_rank_time.py), so the rounds follow the own tile count: 2 up to 128 tiles ... 16 from 1024 on.
+static int list_rounds(const SymArgs& sa) { return std::min(16, std::max(2, (sa.t_hi - sa.t_lo) / 64)); }
+
 hipError_t launch_sym_pair(bool rad, const TickArgs& a, const SymArgs& sa, hipStream_t st) {
     if (a.N <= 1 || !a.en_ped) return hipSuccess;
     dim3 grid(sa.n_t, sa.n_t / 2 + 1);
@@ -2668,7 +2691,7 @@ hipError_t launch_sym_pair(bool rad, const TickArgs& a, const SymArgs& sa, hipSt
         // interleave better with the geometry kernel's workgroups and even out the tail; measured best 4x at 256 tiles, 16x from
         // 1024 tiles on
         static const int rounds_ov = exp_env("SFM_ROUNDS") ? atoi(exp_env("SFM_ROUNDS")) : 0;      // A/B only
-        const int rounds = rounds_ov > 0 ? rounds_ov : std::min(16, std::max(2, sa.n_t / 64));
+        const int rounds = rounds_ov > 0 ? rounds_ov : list_rounds(sa);
         grid = dim3(256 * 8 * rounds);
     }
     const bool cut = sa.vmax != nullptr;           // list cutoff: the per-step reach and exponent tests are on as well
@@ -2680,7 +2703,8 @@ hipError_t launch_sym_pair(bool rad, const TickArgs& a, const SymArgs& sa, hipSt
 // the pair kernel of a list-cutoff tick with the geometry workgroups of the same tick in front (sfm_pair_geo_kernel)
 hipError_t launch_sym_pair_geo(bool rad, const TickArgs& a, const SymArgs& sa, hipStream_t st) {
     const int tiles = ((a.i_end + WAVE - 1) >> 6) - (a.i_begin >> 6);
-    const int rounds = std::min(16, std::max(2, sa.n_t / 64));
+    static const int rounds_ov = exp_env("SFM_ROUNDS") ? atoi(exp_env("SFM_ROUNDS")) : 0;      // A/B only
+    const int rounds = rounds_ov > 0 ? rounds_ov : list_rounds(sa);
     const int n_geo = tiles * a.geo_slices, n_pair = sa.work ? 256 * 8 * rounds : sa.n_t * (sa.n_t / 2 + 1);
     const dim3 grid(n_geo + n_pair);
     // more geometry workgroups than the CUs hold in one round beside the pair workgroups: spread them evenly over the grid

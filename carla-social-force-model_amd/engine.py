@@ -204,6 +204,17 @@ class SfmEngine:
         self.n = n
         self.shard = (0, n)
 
+    def step_packed(self, rows, zvz, v_out, integrate=False, redraw=False):
+        """One host-in-the-loop tick in one call (sfm_step_packed): ``rows`` float32 (N, 9) = {x, y, vx, vy, waypoint x, waypoint y,
+        target_speed, radius, border-force-off flag}, ``zvz`` float32 (N, 2) = {z, vz} or None (planar crowd), v' into ``v_out``
+        float32 (N, 3).  All three C-contiguous; nothing is allocated or converted here."""
+        n = rows.shape[0]
+        self.planar = zvz is None
+        self._check(self._lib.sfm_step_packed(self._h, n, fptr(rows), fptr(zvz), self._flags(integrate, redraw, False), fptr(v_out)),
+                    "sfm_step_packed")
+        self.n = n
+        self.shard = (0, n)
+
     def set_shard(self, i_begin, i_end):
         self._check(self._lib.sfm_set_shard(self._h, int(i_begin), int(i_end)), "sfm_set_shard")
         self.shard = (int(i_begin), int(i_end))

@@ -80,7 +80,12 @@ class PedestrianSimulation:
             self.peds.max_speed_factor = sfm_config.get('max_speed_multiplier', self.peds.max_speed_factor)
         self._staged = {}
         self.engine = SfmEngine(sfm_config, step_length, device=device, honour_file_keys=honour_file_keys)
+        self.engine.set_timing(False)        # no HIP-event bracket around every tick (~11 us): nobody reads it through this class
         self.forces = self.init_forces()
+        # the per-tick exchange with the device: one packed fp32 block up, v' down (sfm_step_packed), buffers kept across ticks
+        self._rows = np.empty((16, 9), dtype=np.float32)
+        self._zvz = np.empty((16, 2), dtype=np.float32)
+        self._vout = np.empty((16, 3), dtype=np.float32)
 
     def init_forces(self):
         """dict force name -> FusedForce in the reference's order (pedestrian_simulation.py:37-48); uploads
@@ -115,17 +120,58 @@ class PedestrianSimulation:
                 planar = True
         self.engine.upload_state(*cols, planar=planar)
 
+    def _step_device(self, peds):
+        """pedestrian_simulation.py:81-83 on the GPU, host record array in, v' out: staged geometry updates, then ONE library call
+        (sfm_step_packed) on one packed fp32 block written straight out of the 132-byte records."""
+        for name, what in self._staged.items():
+            if name == 'dynamic_obstacle_force':
+                self.engine.set_dynamic_obstacles(what.get('obstacles', self.dyn_obstacles), what.get('velocities'))
+            elif name == 'static_obstacle_force' and 'obstacles' in what:
+                self.engine.set_static_obstacles(what['obstacles'])
+        self._staged.clear()
+        n = peds.size()
+        if n > len(self._rows):
+            cap = max(n, 2 * len(self._rows))
+            self._rows, self._zvz, self._vout = (np.empty((cap, w), dtype=np.float32) for w in (9, 2, 3))
+        rows = peds.pack_rows(self._rows)
+        s = peds.state
+        z, vz = s['loc'][:, 2], s['vel'][:, 2]
+        # the 2-D kernels iff all z are equal and no pedestrian has a v_z (then the 3-component formulas of forces.py:74-117 and
+        # stateutils.py:18-23 reduce to them exactly), or -- planar_tolerance -- nearly so (the documented deviation above)
+        z0 = z[0]
+        flat = bool((z == z0).all()) and not bool(vz.any())
+        if not flat and self.planar_tolerance is not None:
+            flat = bool(np.max(np.abs(z - np.median(z))) <= self.planar_tolerance and np.max(np.abs(vz)) <= self.planar_tolerance)
+        zvz = None
+        if not flat:
+            zvz = self._zvz[:n]
+            zvz[:, 0] = z
+            zvz[:, 1] = vz
+        vout = self._vout[:n]
+        self.engine.step_packed(rows, zvz, vout)
+        self.engine._z0 = float(z0)
+        return vout
+
     # ---- one simulation step --------------------------------------------------------------------------------
     def tick(self, sim_time):
         peds = self.peds
         if peds.state is None or peds.size() == 0:              # :60-61
             return
-        peds.apply_current_mode()                                # :63
-        waiting = []
-        for k, fsm in enumerate(peds.mode()):                    # :64-67
-            fsm.tick(sim_time)
-            if fsm.current_mode == PedMode.CHECKING_TRAFFIC:
-                waiting.append(k)
+        peds.apply_current_mode()                                # :63 (cached arrays, rebuilt when a mode object changed)
+        watch = peds.watch
+        watch.sim_time = sim_time
+        if peds._unwatched:                                      # mode objects of another class: the reference's own loop, :64-67
+            waiting = []
+            for k, fsm in enumerate(peds.mode()):
+                fsm.tick(sim_time)
+                if fsm.current_mode == PedMode.CHECKING_TRAFFIC:
+                    waiting.append(k)
+        else:
+            # PedModeManager.tick only ever acts on an IDLE pedestrian (ped_mode_manager.py:30-35): those are the ones visited; the
+            # others' clock is the watch's.  Pedestrians waiting at a kerb are known to the watch as well.
+            for fsm in tuple(watch.idle):
+                fsm.tick(sim_time)
+            waiting = [k for k, fsm in enumerate(peds.mode()) if fsm in watch.checking] if watch.checking else ()
         for k in waiting:                                        # :67-73 gap acceptance
             row = peds.state[k]
             if not self.dyn_obstacles or check_traffic(row, self.dyn_obstacles, self.dyn_obs_vel, self.dyn_obs_extent):
@@ -134,9 +180,7 @@ class PedestrianSimulation:
             peds.record_current_state(sim_time)
             if self.dyn_obstacles:
                 self.record_dyn_obstacle_states(sim_time)
-        self._sync_device(peds)
-        self.engine.tick()                                       # :81-83, fused on the GPU
-        self._publish(self.engine.velocities())
+        self._publish(self._step_device(peds))                   # :81-83, fused on the GPU
 
     def _publish(self, new_vel):
         view = self.peds.state[['id', 'vel']]                    # a view: the write lands in state['vel'] (:123-124)

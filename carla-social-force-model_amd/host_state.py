@@ -44,9 +44,24 @@ _ENTRY_SPEED = {
 }
 
 
+class ModeWatch:
+    """What the PedModeManagers of ONE PedState share (round 4): a version counter that every change of a mode or a mode's target
+    speed bumps, the simulation clock, and the managers currently in the two modes the per-tick host loop cares about.  With it
+    ``PedState.apply_current_mode`` / ``crossing_mask`` are cached arrays instead of a Python loop over N objects every tick, and
+    ``PedestrianSimulation.tick`` visits only the IDLE pedestrians (the only ones whose ``tick`` can do anything,
+    ped_mode_manager.py:30-35) and the ones waiting at a kerb."""
+    __slots__ = ("version", "sim_time", "idle", "checking")
+
+    def __init__(self):
+        self.version, self.sim_time = 0, 0
+        self.idle, self.checking = set(), set()
+
+
 class PedModeManager:
-    """Finite state machine of one pedestrian (ped_mode_manager.py:12-70)."""
+    """Finite state machine of one pedestrian (ped_mode_manager.py:12-70).  ``current_mode`` and ``target_speed`` are plain
+    attributes to every caller; behind them a setter tells the owning PedState's ModeWatch (if any) that something changed."""
     waiting_time = 5    # seconds an IDLE pedestrian waits before walking again
+    _watch = None       # set by PedState.add_pedestrian
 
     def __init__(self, ped_name, target_speed, initial_mode, crossing_speed_factor, crossing_safety_margin):
         self.ped_name = ped_name
@@ -58,6 +73,41 @@ class PedModeManager:
         # NB the initial mode's entry action is not run: an initially IDLE pedestrian keeps its speed
         self.current_mode = initial_mode
         self.target_speed = target_speed
+
+    @property
+    def current_mode(self):
+        return self._mode
+
+    @current_mode.setter
+    def current_mode(self, mode):
+        self._mode = mode
+        w = self._watch
+        if w is not None:
+            w.version += 1
+            w.idle.discard(self); w.checking.discard(self)
+            if mode == PedMode.IDLE:
+                w.idle.add(self)
+            elif mode == PedMode.CHECKING_TRAFFIC:
+                w.checking.add(self)
+
+    @property
+    def target_speed(self):
+        return self._target_speed
+
+    @target_speed.setter
+    def target_speed(self, v):
+        self._target_speed = v
+        if self._watch is not None:
+            self._watch.version += 1
+
+    def _attach(self, watch):
+        """Join (or, watch None, leave) a PedState's ModeWatch."""
+        old = self._watch
+        if old is not None:
+            old.idle.discard(self); old.checking.discard(self); old.version += 1
+        self._watch = watch
+        if watch is not None:
+            self.current_mode = self._mode           # registers the mode with the new watch
 
     def tick(self, sim_time):
         self.sim_time = sim_time
@@ -75,7 +125,10 @@ class PedModeManager:
             attr = _ENTRY_SPEED[mode]
             self.target_speed = 0 if attr is None else getattr(self, attr)
         if mode == PedMode.IDLE:
-            self.next_mode_time = self.sim_time + self.waiting_time
+            # the time of the last tick (ped_mode_manager.py:52: self.sim_time) -- a watched manager that is not IDLE is not
+            # ticked one by one any more, the watch's clock is what its own sim_time would have been
+            now = self.sim_time if self._watch is None else max(self.sim_time, self._watch.sim_time)
+            self.next_mode_time = now + self.waiting_time
         self.current_mode = mode
 
 
@@ -97,6 +150,11 @@ class PedState:
         self._buf = None
         self._n = 0
         self.all_states = {}        # sim_time -> snapshot, filled by record_current_state
+        self.watch = ModeWatch()    # shared by the mode managers of this crowd
+        self._unwatched = 0         # mode objects of another class (e.g. the reference's own): no caching while there are any
+        self._cache_version = -1    # watch.version the cached arrays below belong to
+        self._cache_n = -1
+        self._ts_cache = self._cross_cache = self._mode_cache = None
 
     # ``state`` is None until the first spawn, then a view of the live rows (callers write through it)
     @property
@@ -105,8 +163,26 @@ class PedState:
 
     @state.setter
     def state(self, arr):
+        self._watch_rows(False)
         self._buf = None if arr is None else np.array(arr, dtype=self.ped_state_dtype, ndmin=1)
         self._n = 0 if arr is None else len(self._buf)
+        self._watch_rows(True)
+
+    def _watch_rows(self, attach):
+        """(Un)register the mode objects of the live rows with this crowd's ModeWatch."""
+        self._unwatched = 0
+        for m in ([] if self._buf is None else self._buf[:self._n]['mode']):
+            if isinstance(m, PedModeManager):
+                m._attach(self.watch if attach else None)
+            elif attach:
+                self._unwatched += 1
+        self.invalidate_modes()
+
+    def invalidate_modes(self):
+        """Forget the cached target speeds / crossing mask.  Spawning, removing, ``set_mode`` and assignments to a manager's
+        ``current_mode`` / ``target_speed`` do it by themselves; call it after putting ANOTHER mode object into ``state['mode']``
+        by hand (the reference's callers never do: pedestrian_spawner.py:230-243 builds the object once per pedestrian)."""
+        self._cache_version = -1
 
     def add_pedestrian(self, initial_ped_state):
         """(name, id, loc3, vel3, first_waypoint3, PedModeManager, radius, target_speed)"""
@@ -117,14 +193,26 @@ class PedState:
             grown[:self._n] = self._buf
             self._buf = grown
         self._buf[self._n] = tuple(initial_ped_state)
+        m = self._buf[self._n]['mode']
+        if isinstance(m, PedModeManager):
+            m._attach(self.watch)
+        else:
+            self._unwatched += 1
         self._n += 1
+        self.invalidate_modes()
 
     def remove_pedestrian(self, ped_name):
         keep = self.state['name'] != ped_name
+        for m in self.state['mode'][~keep]:
+            if isinstance(m, PedModeManager):
+                m._attach(None)
+            else:
+                self._unwatched -= 1
         k = int(keep.sum())
         self._buf[:k] = self._buf[:self._n][keep]
         self._buf[k:self._n]['mode'] = None            # drop references to the removed mode objects
         self._n = k
+        self.invalidate_modes()
 
     def size(self):
         return self._n
@@ -156,9 +244,24 @@ class PedState:
         # IndexError for an unknown name, as in the reference (pedestrian_state.py:92)
         self.state['mode'][rows[0]].set_mode(PedMode.CROSSING_ROAD if is_crossing else PedMode.WALKING_SIDEWALK)
 
+    def _refresh_mode_caches(self):
+        """Target speeds, border-force mask and modes of the live rows as arrays -- rebuilt only when a mode object said that
+        something changed (ModeWatch.version), a row came or went, or some mode object is not one of ours."""
+        w = self.watch
+        if self._unwatched == 0 and self._cache_version == w.version and self._cache_n == self._n:
+            return
+        version = w.version
+        modes = self.state['mode']
+        self._ts_cache = np.fromiter((m.target_speed for m in modes), dtype=np.float64, count=self._n)
+        self._mode_cache = [m.current_mode for m in modes]
+        self._cross_cache = np.fromiter((c in BORDER_FREE_MODES for c in self._mode_cache), dtype=bool, count=self._n)
+        self._cache_version, self._cache_n = version, self._n
+
     def apply_current_mode(self):
-        self.state['target_speed'] = np.fromiter((m.target_speed for m in self.state['mode']),
-                                                 dtype=np.float64, count=self._n)
+        """state['target_speed'] <- the mode objects' target speeds (pedestrian_state.py:94-95), every tick: whatever a caller
+        wrote into the column in between is overwritten, as in the reference."""
+        self._refresh_mode_caches()
+        self.state['target_speed'] = self._ts_cache
 
     def desired_directions(self):
         """Unit xy direction to the waypoint, z = 0 (stateutils.py:7-15)."""
@@ -170,7 +273,8 @@ class PedState:
 
     def record_current_state(self, sim_time):
         snapshot = self.state.copy()
-        snapshot['mode'] = [m.current_mode for m in self.state['mode']]
+        self._refresh_mode_caches()
+        snapshot['mode'] = self._mode_cache
         self.all_states[sim_time] = snapshot
 
     def get_all_states(self):
@@ -178,8 +282,22 @@ class PedState:
 
     # ---- what the device consumes -------------------------------------------------------------------
     def crossing_mask(self):
-        return np.fromiter((m.current_mode in BORDER_FREE_MODES for m in self.state['mode']),
-                           dtype=bool, count=self._n)
+        self._refresh_mode_caches()
+        return self._cross_cache
+
+    def pack_rows(self, out):
+        """The numeric columns the device consumes as ONE fp32 block, written into ``out[:n]`` (float32, shape (cap, 9)):
+        {x, y, vx, vy, waypoint x, waypoint y, target_speed, radius, border-force-off flag}.  Six strided assignments straight out
+        of the 132-byte records (no per-column copies, no float64 intermediates)."""
+        s, n = self.state, self._n
+        o = out[:n]
+        o[:, 0:2] = s['loc'][:, :2]
+        o[:, 2:4] = s['vel'][:, :2]
+        o[:, 4:6] = s['next_waypoint'][:, :2]
+        o[:, 6] = s['target_speed']
+        o[:, 7] = s['radius']
+        o[:, 8] = self.crossing_mask()
+        return o
 
     def numeric_columns(self):
         """(loc, vel, next_waypoint, target_speed, radius, crossing_mask), contiguous copies gathered

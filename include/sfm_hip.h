@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SFM_ABI_VERSION 3   /* 2: + sfm_tick_begin / sfm_tick_end, sfm_set_partition, sfm_get_pair_work; 3: + sfm_set_timing (additions only) */
+#define SFM_ABI_VERSION 4   /* 2: + sfm_tick_begin / sfm_tick_end, sfm_set_partition, sfm_get_pair_work; 3: + sfm_set_timing; 4: + sfm_step_packed (additions only) */
 
 typedef struct SfmHandle SfmHandle;
 
@@ -193,6 +193,15 @@ int sfm_run_recorded(SfmHandle* h, int ticks, uint32_t flags, int stride, float*
 /* get_new_velocities (pedestrian_simulation.py:126-127): v' of this handle's shard rows, written at
  * [i_begin, i_end) of the caller's length-N arrays.  vz may be NULL. */
 int sfm_download_velocities(SfmHandle* h, float* vx, float* vy, float* vz);
+/* One host-in-the-loop tick in one call (ABI 4): PedestrianSimulation.tick's numeric part as the reference's main loop drives it
+ * (run_simulation.py:87-114: update_ped_info -> tick -> get_new_velocities; pedestrian_simulation.py:57-83, pedestrian_state.py:79-95)
+ * = sfm_upload_state + sfm_tick + sfm_download_velocities on one packed block.
+ *   rows  [N][9]  {x, y, vx, vy, waypoint x, waypoint y, target_speed, radius, border-force-off flag (0 / 1)}
+ *   zvz   [N][2]  {z, vz}, or NULL: planar crowd (all z equal, no v_z)
+ *   v_out [N][3]  {vx', vy', vz'}, the caller's index order.
+ * Errors as the three calls it stands for. */
+int sfm_step_packed(SfmHandle* h, int N, const float* rows, const float* zvz, uint32_t flags, float* v_out);
+
 /* Whole numeric state of the shard rows (any pointer may be NULL to skip that column). */
 int sfm_download_state(SfmHandle* h, float* x, float* y, float* z, float* vx, float* vy, float* vz,
                        float* wx, float* wy);

@@ -185,3 +185,46 @@ def test_planar_tolerance_is_an_opt_in_deviation():
     assert np.allclose(v[:, :2], flat_v[:, :2], rtol=1e-5, atol=1e-7)
     # and the deviation is small but real: the exact 3-D evaluation of the bumpy crowd is not the flat one
     assert not np.array_equal(variants[None][1][:, :2], v[:, :2])
+
+
+def test_mode_changes_between_ticks_are_honoured():
+    """Round 4: the facade keeps target speeds and the border-force mask as cached arrays (host_state.ModeWatch) and ticks only IDLE
+    pedestrians' FSMs.  Whatever a caller does to a mode between two ticks -- update_next_waypoint onto a crossing (run_simulation.py:
+    124-126), a mode object's target_speed written directly, an IDLE pedestrian whose waiting time runs out during the run -- must
+    reach the device at the next tick: v' against the oracle fed with the target speeds / mask the reference's tick would have
+    used (pedestrian_simulation.py:63-65, forces.py:176-177)."""
+    c = gio.Case(CASES["all_s1_n256"])
+    sim = _build(c)
+    prm = O.OracleParams.from_config(c.cfg)
+    geom = O.Geometry(c.borders, c.border_centers, c.border_lengths, c.static_obstacles, c.dynamic_obstacles, c.dynamic_vel)
+    sim.record_states = False
+    sim.dyn_obstacles = []                 # (no gap acceptance in this test: a pedestrian sent to CHECKING_TRAFFIC crosses at once, :70)
+    try:
+        mgr = sim.peds.mode()
+        t = 0.0
+        for step in range(4):
+            if step == 1:
+                sim.peds.update_next_waypoint("ped_3", (np.array([1.0, 2.0, 0.0]), True))     # -> CHECKING -> (tick) CROSSING_ROAD
+                mgr[7].target_speed = 0.5                                                       # a direct write to the mode object
+                mgr[11].set_mode(PedMode.IDLE)                                                  # stands still for waiting_time
+            if step == 3:
+                t = 6.0                                                                         # ped_11 wakes up: 0.05 + 5 <= 6
+            loc, vel, wp = sim.peds.loc().copy(), sim.peds.vel().copy(), sim.peds.next_waypoint().copy()
+            sim.tick(t)
+            modes = np.array([int(m.current_mode) for m in mgr])
+            ts = np.array([float(m.target_speed) for m in mgr])                                 # what the NEXT tick will apply ...
+            used_ts = sim.peds.target_speed().copy()                                            # ... and what THIS tick applied
+            if step == 1:
+                assert modes[3] == PedMode.CROSSING_ROAD and used_ts[3] == 0 and used_ts[7] == 0.5 and used_ts[11] == 0
+            if step == 2:
+                assert used_ts[3] == pytest.approx(1.5 * c.target_speed[3]) and modes[11] == PedMode.IDLE
+            if step == 3:
+                assert modes[11] == PedMode.WALKING_SIDEWALK and used_ts[11] == 0 and ts[11] > 0   # the tick reads speeds BEFORE mode.tick (:63-65)
+            crossing = (modes == 2) | (modes == 3)
+            d = {}
+            with np.errstate(all="ignore"):
+                _, total, _ = O.tick_forces(loc, vel, wp, used_ts, c.radius, crossing, geom, prm, theta_tol=P.THETA_TOL, tie_rel=P.TIE_REL, diag=d)
+            P.check_velocity(sim.get_new_velocities()['vel'], O.new_velocities(vel, total, used_ts, c.dt), d["total"][0], c.dt)
+            t += c.dt
+    finally:
+        sim.close()

@@ -300,3 +300,63 @@ def test_bench_flags_counters_from_another_build_as_stale(tmp_path, monkeypatch)
     monkeypatch.undo()
     pmc, stamp = bench.pmc_counters("c2", "sfm_fused_tick_kernel")
     assert "SQ_INSTS_VALU" in pmc and "VALU_PER_64_PAIR_STEP" in pmc and stamp["counters_stale"] is False
+
+
+def test_mode_caches_follow_every_way_a_mode_can_change():
+    """Round 4: ``apply_current_mode`` / ``crossing_mask`` are cached arrays, rebuilt when a mode object says that something changed
+    (ModeWatch.version).  Every way the reference's callers change a mode or a target speed must get through -- set_mode
+    (pedestrian_state.py:88-92), the FSM's own tick (ped_mode_manager.py:30-35), a direct write to a manager's attribute, spawn and
+    removal -- and a write into state['target_speed'] is overwritten at the next tick like in the reference (pedestrian_state.py:94-95).
+    A mode object of another class (the reference's own PedModeManager) switches the caching off."""
+    from carla_social_force_model_amd.host_state import PedState
+    ps = PedState({})
+    mgrs = [PedModeManager(f"p{i}", 1.0 + 0.1 * i, PedMode.WALKING_SIDEWALK, 1.5, 1.0) for i in range(5)]
+    for i, m in enumerate(mgrs):
+        ps.add_pedestrian((f"p{i}", i, np.zeros(3), np.zeros(3), np.ones(3), m, 0.3, 9.9))
+    ps.apply_current_mode()
+    assert np.allclose(ps.target_speed(), [1.0, 1.1, 1.2, 1.3, 1.4]) and not ps.crossing_mask().any()
+    v0 = ps.watch.version
+    ps.apply_current_mode()
+    assert ps.watch.version == v0                                     # nothing changed: nothing rebuilt
+    ps.state['target_speed'][2] = 7.0                                 # a caller's write is overwritten at the next tick
+    ps.apply_current_mode()
+    assert ps.target_speed()[2] == pytest.approx(1.2)
+    ps.update_next_waypoint("p1", (np.array([5.0, 5.0, 0.0]), True))  # WALKING -> asked to cross -> CHECKING_TRAFFIC: stands still
+    ps.apply_current_mode()
+    assert ps.target_speed()[1] == 0 and mgrs[1] in ps.watch.checking and not ps.crossing_mask()[1]
+    mgrs[1].set_mode(PedMode.CROSSING_ROAD)                           # gap accepted (pedestrian_simulation.py:70)
+    ps.apply_current_mode()
+    assert ps.target_speed()[1] == pytest.approx(1.5 * 1.1) and ps.crossing_mask()[1] and mgrs[1] not in ps.watch.checking
+    mgrs[3].target_speed = 0.25                                       # a direct write to the mode object
+    ps.apply_current_mode()
+    assert ps.target_speed()[3] == 0.25
+    # an IDLE pedestrian: only it is ticked one by one; it wakes up waiting_time after the WATCH's clock, not its own stale one
+    ps.watch.sim_time = 12.0
+    mgrs[4].set_mode(PedMode.IDLE)
+    assert mgrs[4] in ps.watch.idle and mgrs[4].next_mode_time == 17.0
+    ps.apply_current_mode()
+    assert ps.target_speed()[4] == 0
+    for m in tuple(ps.watch.idle):
+        m.tick(16.9)
+    assert mgrs[4].current_mode == PedMode.IDLE
+    for m in tuple(ps.watch.idle):
+        m.tick(17.0)
+    ps.apply_current_mode()
+    assert mgrs[4].current_mode == PedMode.WALKING_SIDEWALK and not ps.watch.idle and ps.target_speed()[4] == pytest.approx(1.4)
+    ps.remove_pedestrian("p1")                                        # rows shift: the arrays follow
+    ps.apply_current_mode()
+    assert ps.size() == 4 and np.allclose(ps.target_speed(), [1.0, 1.2, 0.25, 1.4]) and not ps.crossing_mask().any()
+    assert mgrs[1]._watch is None
+    rows = ps.pack_rows(np.empty((8, 9), np.float32))
+    assert rows.shape == (4, 9) and np.allclose(rows[:, 6], [1.0, 1.2, 0.25, 1.4]) and np.allclose(rows[:, 7], 0.3) and not rows[:, 8].any()
+
+    class Foreign:                                                    # e.g. the reference's own class: no hooks, no caching
+        def __init__(self):
+            self.target_speed, self.current_mode = 0.9, PedMode.CROSSING_ROAD
+    f = Foreign()
+    ps.add_pedestrian(("px", 9, np.zeros(3), np.zeros(3), np.ones(3), f, 0.3, 0.0))
+    ps.apply_current_mode()
+    assert ps.target_speed()[-1] == 0.9 and ps.crossing_mask()[-1]
+    f.target_speed, f.current_mode = 0.4, PedMode.WALKING_SIDEWALK   # a silent change is still seen: every tick re-reads the objects
+    ps.apply_current_mode()
+    assert ps.target_speed()[-1] == 0.4 and not ps.crossing_mask()[-1]
