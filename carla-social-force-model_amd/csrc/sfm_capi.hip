@@ -34,6 +34,7 @@ struct ReorderBufs { unsigned long long *key64_in, *key64_out; uint32_t *row_a, 
 size_t reorder_temp_bytes(int N);
 hipError_t launch_resort(const float4* pk, int N, int strip_rows, const ReorderBufs& b, hipStream_t st);
 hipError_t launch_resort_blocks(const float4* pk, int N, const BlockPlan& pl, const ReorderBufs& b, hipStream_t st);
+hipError_t launch_unpack_geo(const char* block, float4* ctr, int K, float2* pts, int P, int* off, bool with_off, hipStream_t st);
 hipError_t launch_unpack_rows(const char* block, size_t b_own, size_t b_zv, size_t b_rr, size_t b_cm, int n_pad, float4* pk0,
                               float4* pk1, float4* own, float2* zv0, float2* zv1, float* radius, uint8_t* crossing, uint32_t* draws,
                               hipStream_t st);
@@ -64,6 +65,7 @@ struct DevGeo {
     size_t off_cap = 0, pts_cap = 0, ctr_cap = 0;      // grow-only (the dynamic obstacles arrive every tick)
     char* stage = nullptr;                              // pinned host block the three arrays are copied from, asynchronously
     size_t stage_cap = 0;
+    std::vector<int> off_host;                          // the offsets the device holds (vehicles arrive every tick with the same ring sizes: not copied again)
 };
 
 struct SfmHandle {
@@ -161,6 +163,9 @@ struct SfmHandle {
     float4* dyn_ctr_alt = nullptr;         // device-side vehicles in the fused tick: the NEXT tick's centres / rings (ping-pong with dynamics.ctr / .pts)
     float2* dyn_pts_alt = nullptr;
     size_t dyn_ctr_alt_cap = 0, dyn_pts_alt_cap = 0;
+    bool hosted = false;                   // inside sfm_step_packed: the tick's last kernel also writes the new rows to down_stage
+    char* down_stage = nullptr;            // pinned host block [N_pad float4 | N_pad float2] the device writes v' into
+    size_t down_stage_cap = 0;
     std::vector<float> step_cols;          // sfm_step_packed: the packed block taken apart into the columns sfm_upload_state consumes
     std::vector<uint8_t> step_mask;
     unsigned long long* fused_stamps = nullptr;   // experiments build, SFM_FUSED_STAMPS=<file>: phase stamps of the last fused launch
@@ -461,6 +466,7 @@ int sfm_destroy(SfmHandle* h) {
     if (h->tile_vmax) hipFree(h->tile_vmax);
     if (h->strip_box) hipFree(h->strip_box);
     if (h->up_stage) hipHostFree(h->up_stage);
+    if (h->down_stage) hipHostFree(h->down_stage);
     if (h->up_block) hipFree(h->up_block);
     if (h->strip_vmax) hipFree(h->strip_vmax);
     if (h->work) hipFree(h->work);
@@ -508,7 +514,10 @@ static int set_geo(SfmHandle* h, DevGeo& g, int K, const int32_t* offsets, const
         if (offsets[k + 1] < offsets[k]) return fail(h, SFM_ERR_INVALID, "offsets must be non-decreasing");
     const int P = offsets[K];
     if (P > 0 && (!px || !py)) return fail(h, SFM_ERR_INVALID, "point arrays are NULL");
+    const int* off_before = g.off;
     HIP_TRY(h, dev_reserve(g.off, g.off_cap, (size_t)K + 1));
+    const bool off_same = g.off == off_before && g.K == K && g.off_host.size() == (size_t)K + 1 &&
+                          memcmp(g.off_host.data(), offsets, sizeof(int) * ((size_t)K + 1)) == 0;
     HIP_TRY(h, dev_reserve(g.pts, g.pts_cap, (size_t)(P > 0 ? P : 1)));
     HIP_TRY(h, dev_reserve(g.ctr, g.ctr_cap, (size_t)K));
     // [ctr | pts | off] assembled in one pinned block, copied asynchronously (the stream was drained above, so the block
@@ -525,9 +534,15 @@ static int set_geo(SfmHandle* h, DevGeo& g, int K, const int32_t* offsets, const
     float2* sp = reinterpret_cast<float2*>(g.stage + b_pts);
     for (int p = 0; p < P; ++p) sp[p] = make_float2(px[p], py[p]);
     memcpy(g.stage + b_off, offsets, sizeof(int) * ((size_t)K + 1));
-    HIP_TRY(h, hipMemcpyAsync(g.ctr, g.stage + b_ctr, sizeof(float4) * (size_t)K, hipMemcpyHostToDevice, h->stream));
-    if (P > 0) HIP_TRY(h, hipMemcpyAsync(g.pts, g.stage + b_pts, sizeof(float2) * (size_t)P, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(g.off, g.stage + b_off, sizeof(int) * ((size_t)K + 1), hipMemcpyHostToDevice, h->stream));
+    if (bytes <= ((size_t)64 << 10)) {
+        // a handful of polylines (the vehicles the simulator reports every tick): one launch reads the pinned block over the bus
+        HIP_TRY(h, launch_unpack_geo(g.stage, g.ctr, K, g.pts, P, g.off, !off_same, h->stream));
+    } else {
+        HIP_TRY(h, hipMemcpyAsync(g.ctr, g.stage + b_ctr, sizeof(float4) * (size_t)K, hipMemcpyHostToDevice, h->stream));
+        if (P > 0) HIP_TRY(h, hipMemcpyAsync(g.pts, g.stage + b_pts, sizeof(float2) * (size_t)P, hipMemcpyHostToDevice, h->stream));
+        if (!off_same) HIP_TRY(h, hipMemcpyAsync(g.off, g.stage + b_off, sizeof(int) * ((size_t)K + 1), hipMemcpyHostToDevice, h->stream));
+    }
+    if (!off_same) g.off_host.assign(offsets, offsets + K + 1);
     g.K = K;
     g.P = P;
     return SFM_OK;
@@ -602,6 +617,23 @@ int sfm_set_dynamic_obstacles(SfmHandle* h, int M, const int32_t* offsets, const
     std::vector<float4> c4((size_t)(M > 0 ? M : 0));
     for (int k = 0; k < M; ++k)       // velocities default to 0 like ObstacleForce (forces.py:212-213)
         c4[k] = make_float4(cx[k], cy[k], vx ? vx[k] : 0.f, vy ? vy[k] : 0.f);
+    h->dyn_boxes = false;
+    return set_geo(h, h->dynamics, M, offsets, px, py, c4);
+}
+
+// The same from packed arrays (ABI 4, additions only): pts [P][2] {x, y}, cv [M][4] {cx, cy, vx, vy} -- what a caller that receives the
+// vehicles every tick (run_simulation.py:95) can fill with two array writes.
+int sfm_set_dynamic_obstacles_packed(SfmHandle* h, int M, const int32_t* offsets, const float* pts, const float* cv) {
+    if (!h) return SFM_ERR_INVALID;
+    if (M > 0 && (!offsets || !cv)) return fail(h, SFM_ERR_INVALID, "offsets / cv is NULL");
+    const int P = M > 0 ? offsets[M] : 0;
+    if (P > 0 && !pts) return fail(h, SFM_ERR_INVALID, "pts is NULL");
+    std::vector<float>& c = h->step_cols;          // (scratch shared with sfm_step_packed: both run on the caller's thread, one after the other)
+    c.resize((size_t)2 * (size_t)(P > 0 ? P : 0) + 1);
+    float *px = c.data(), *py = px + (P > 0 ? P : 0);
+    for (int p = 0; p < P; ++p) { px[p] = pts[2 * p]; py[p] = pts[2 * p + 1]; }
+    std::vector<float4> c4((size_t)(M > 0 ? M : 0));
+    for (int k = 0; k < M; ++k) c4[k] = make_float4(cv[4 * k], cv[4 * k + 1], cv[4 * k + 2], cv[4 * k + 3]);
     h->dyn_boxes = false;
     return set_geo(h, h->dynamics, M, offsets, px, py, c4);
 }
@@ -779,10 +811,17 @@ int sfm_upload_state(SfmHandle* h, int N, const float* x, const float* y, const 
         if (radius) rr[s_] = radius[i];
         if (crossing_mask) cm[s_] = crossing_mask[i] ? 1 : 0;
     }
-    HIP_TRY(h, dev_reserve(h->up_block, h->up_block_cap, b_end));
-    HIP_TRY(h, hipMemcpyAsync(h->up_block, h->up_stage, b_end, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, launch_unpack_rows(h->up_block, b_own, b_zv, b_rr, b_cm, n_pad, h->pk[0], h->pk[1], h->own, h->zv[0], h->zv[1],
-                                  h->radius, h->crossing, h->draws, h->stream));
+    if (b_end <= ((size_t)256 << 10)) {
+        // a host-in-the-loop crowd (round 4): the unpack kernel reads the pinned block over the bus by itself -- one launch instead of
+        // a copy and a launch in front of every tick (the block is not overwritten before the next upload's stream synchronisation)
+        HIP_TRY(h, launch_unpack_rows(h->up_stage, b_own, b_zv, b_rr, b_cm, n_pad, h->pk[0], h->pk[1], h->own, h->zv[0], h->zv[1],
+                                      h->radius, h->crossing, h->draws, h->stream));
+    } else {
+        HIP_TRY(h, dev_reserve(h->up_block, h->up_block_cap, b_end));
+        HIP_TRY(h, hipMemcpyAsync(h->up_block, h->up_stage, b_end, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, launch_unpack_rows(h->up_block, b_own, b_zv, b_rr, b_cm, n_pad, h->pk[0], h->pk[1], h->own, h->zv[0], h->zv[1],
+                                      h->radius, h->crossing, h->draws, h->stream));
+    }
     if (h->reordered) {
         HIP_TRY(h, hipMemcpyAsync(h->ids, h->perm.data(), sizeof(uint32_t) * (size_t)N, hipMemcpyHostToDevice, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));          // perm is pageable and may be resized by the next upload
@@ -960,6 +999,8 @@ static void fill_args(SfmHandle* h, TickArgs& a, uint32_t flags) {
     a.draws = h->draws;
     a.ids = h->reordered ? h->ids : nullptr;
     a.rec = (flags & SFM_TICK_RECORD_FORCES) ? h->rec : nullptr;
+    a.host_pk = h->hosted ? reinterpret_cast<float4*>(h->down_stage) : nullptr;
+    a.host_zv = h->hosted ? reinterpret_cast<float2*>(h->down_stage + sizeof(float4) * (size_t)h->N_pad) : nullptr;
     a.N = h->N; a.N_pad = h->N_pad; a.i_begin = h->i_begin; a.i_end = h->i_end;
     const bool any_geo = (p.enabled[SFM_FORCE_BORDER] && h->borders.K > 0) || (p.enabled[SFM_FORCE_STATIC_OBSTACLE] && h->statics.K > 0) ||
                          (p.enabled[SFM_FORCE_DYNAMIC_OBSTACLE] && h->dynamics.K > 0);
@@ -1637,19 +1678,23 @@ int sfm_step_packed(SfmHandle* h, int N, const float* rows, const float* zvz, ui
         if (zvz) { z[i] = zvz[2 * i]; vz[i] = zvz[2 * i + 1]; }
     }
     int rc = sfm_upload_state(h, N, x, y, zvz ? z : nullptr, vx, vy, zvz ? vz : nullptr, wx, wy, ts, rr, cm);
-    if (rc) return rc;
-    rc = run_ticks(h, 1, flags);
     if (rc || N == 0) return rc;
-    rc = sync_perm(h);
+    // v' of all rows (the upload reset the shard): the tick's last kernel writes the new rows into a pinned host block as well, so
+    // after the stream has drained they are simply there -- no device-to-host copy on the way back
+    const size_t np_ = (size_t)h->N_pad;
+    const size_t need = (sizeof(float4) + sizeof(float2)) * np_;
+    if (need > h->down_stage_cap) {
+        if (h->down_stage) { hipHostFree(h->down_stage); h->down_stage = nullptr; h->down_stage_cap = 0; }
+        HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&h->down_stage), need + need / 2, 0));
+        h->down_stage_cap = need + need / 2;
+    }
+    h->hosted = true;
+    rc = run_ticks(h, 1, flags);
+    h->hosted = false;
     if (rc) return rc;
-    // v' of the rows [i_begin, i_end) = all of them (the upload reset the shard), through the pinned block of the upload
-    const size_t need = sizeof(float4) * n + (h->z3 ? sizeof(float2) * n : 0);
-    if (need > h->up_stage_cap) return fail(h, SFM_ERR_STATE, "staging block smaller than the state it has just carried");
-    float4* pk = reinterpret_cast<float4*>(h->up_stage);
-    float2* zv = reinterpret_cast<float2*>(h->up_stage + sizeof(float4) * n);
-    HIP_TRY(h, hipMemcpyAsync(pk, h->pk[h->cur], sizeof(float4) * n, hipMemcpyDeviceToHost, h->stream));
-    if (h->z3) HIP_TRY(h, hipMemcpyAsync(zv, h->zv[h->cur], sizeof(float2) * n, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const float4* pk = reinterpret_cast<const float4*>(h->down_stage);
+    const float2* zv = reinterpret_cast<const float2*>(h->down_stage + sizeof(float4) * np_);
     for (size_t s_ = 0; s_ < n; ++s_) {
         const size_t i = h->perm[s_];
         v_out[3 * i] = pk[s_].z; v_out[3 * i + 1] = pk[s_].w; v_out[3 * i + 2] = h->z3 ? zv[s_].y : 0.f;

@@ -83,6 +83,8 @@ struct TickArgs {
     uint32_t* draws;          // waypoint draw counters
     const uint32_t* ids;      // caller's index of the pedestrian in each row (spatial reordering); null = identity
     float* rec;               // optional per-force record, layout [6][3][N]
+    float4* host_pk;          // sfm_step_packed: the new rows are ALSO written here -- pinned host memory the device reaches by itself --
+    float2* host_zv;          // so the caller's v' needs no copy after the tick (null: off)
     float* geo;               // geometry forces of this tick, layout [geo_slices][6][N_pad]: {fbx,fby,fsx,fsy,fdx,fdy}; null = none
     DynAdvance adv;
     int geo_slices;           // few tiles (small crowds): the polylines of a tile are split over this many workgroups, each

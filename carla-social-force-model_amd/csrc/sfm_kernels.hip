@@ -1261,6 +1261,7 @@ __global__ __launch_bounds__(BLOCK) void sfm_tick_kernel(const TickArgs a) {
         if (lane == 0) {
             a.pk_next[i] = make_float4(nx, ny, nvx, nvy);
             if (Z3) a.zv_next[i] = make_float2(nz, nvz);
+            if (a.host_pk) { a.host_pk[i] = make_float4(nx, ny, nvx, nvy); if (Z3) a.host_zv[i] = make_float2(nz, nvz); }
             if (redraw) { a.own[i] = make_float4(wx, wy, o.z, o.w); if (!a.fsm.mode) a.draws[i] = nd; }
             if (a.rec) {
                 float* rc = a.rec;
@@ -2038,6 +2039,7 @@ __global__ __launch_bounds__(EW * WAVE) void sfm_sym_epilogue_kernel(const TickA
     if (despawn || gone) { const float2 pp = park_position(pid); nx = pp.x; ny = pp.y; nvx = 0.f; nvy = 0.f; nvz = 0.f; }
     if (live) a.pk_next[i] = make_float4(nx, ny, nvx, nvy);
     if (Z3 && live) a.zv_next[i] = make_float2(nz, nvz);
+    if (a.host_pk && live) { a.host_pk[i] = make_float4(nx, ny, nvx, nvy); if (Z3) a.host_zv[i] = make_float2(nz, nvz); }
     if (a.tile_box_out) {                             // whole crowd under the list cutoff: box and largest speed of the tile in the NEXT state
         const float inf = __builtin_inff();
         const bool in_box = live && fabsf(nx) < 1.0e14f;

@@ -84,6 +84,29 @@ hipError_t launch_unpack_rows(const char* block, size_t b_own, size_t b_zv, size
     return hipGetLastError();
 }
 
+// set_geo for a small polyline set that arrives every tick (the simulator's vehicles, obstacles.py:297-329): ONE launch reads the
+// pinned host block [ctr | pts | off] over the bus and spreads it over the three device arrays, instead of three small copies
+// (round 4: ~8 us each in front of every host-in-the-loop tick).  Word copies; a few KiB.
+__global__ void sfm_unpack_geo_kernel(const uint32_t* __restrict__ block, uint32_t* __restrict__ ctr, int w_ctr, uint32_t* __restrict__ pts,
+                                      int w_pts, uint32_t* __restrict__ off, int w_off) {
+    const int total = w_ctr + w_pts + w_off;
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < total; q += gridDim.x * blockDim.x) {
+        const uint32_t v = block[q];
+        if (q < w_ctr) ctr[q] = v;
+        else if (q < w_ctr + w_pts) pts[q - w_ctr] = v;
+        else if (off) off[q - w_ctr - w_pts] = v;
+    }
+}
+
+hipError_t launch_unpack_geo(const char* block, float4* ctr, int K, float2* pts, int P, int* off, bool with_off, hipStream_t st) {
+    const int w_ctr = 4 * K, w_pts = 2 * P, w_off = K + 1;
+    const int total = w_ctr + w_pts + w_off;
+    hipLaunchKernelGGL(sfm_unpack_geo_kernel, dim3(std::min(64, (total + 255) / 256)), dim3(256), 0, st,
+                       reinterpret_cast<const uint32_t*>(block), reinterpret_cast<uint32_t*>(ctr), w_ctr, reinterpret_cast<uint32_t*>(pts), w_pts,
+                       with_off ? reinterpret_cast<uint32_t*>(off) : nullptr, w_off);
+    return hipGetLastError();
+}
+
 __device__ __forceinline__ int plan_block_of(const BlockPlan& pl, int r) {       // block holding rank r of the block order
     int b = 0;
     while (b + 1 < pl.n_blocks && r >= pl.bound[b + 1]) ++b;

@@ -137,20 +137,59 @@ class SfmEngine:
                                                        fptr(cx), fptr(cy)), "sfm_set_static_obstacles")
 
     def set_dynamic_obstacles(self, obstacles, velocities=None):
-        """obstacles as above + velocities (M,2) or None (zeros, forces.py:212-213)."""
+        """obstacles as above + velocities (M,2) or None (zeros, forces.py:212-213).  The simulator reports the vehicles every tick
+        (run_simulation.py:95, obstacles.py:297-329) with rings of unchanged sizes: offsets and fp32 buffers are kept across calls
+        and only refilled."""
         if obstacles is None or len(obstacles) == 0:
             self._check(self._lib.sfm_set_dynamic_obstacles(self._h, 0, None, None, None, None, None, None, None),
                         "sfm_set_dynamic_obstacles")
             return
-        off, px, py, cx, cy = self._obstacles(obstacles)
         M = len(obstacles)
-        if velocities is None:
-            vx = vy = None
-        else:
+        rings = [r for _, r in obstacles]
+        lens = tuple(len(r) for r in rings)
+        c = getattr(self, "_dyn_bufs", None)
+        if c is None or c[0] != lens:
+            off = np.zeros(M + 1, dtype=np.int32)
+            off[1:] = np.cumsum(lens)
+            P = int(off[-1])
+            c = self._dyn_bufs = (lens, off, np.empty((max(P, 1), 2)), np.empty(max(P, 1), np.float32), np.empty(max(P, 1), np.float32),
+                                  *(np.empty(M, np.float32) for _ in range(4)))
+        _, off, pts, px, py, cx, cy, vx, vy = c
+        P = int(off[-1])
+        if P:
+            np.concatenate([np.reshape(r, (-1, 2)) for r in rings], axis=0, out=pts[:P])
+            px[:P] = pts[:P, 0]
+            py[:P] = pts[:P, 1]
+        cs = np.array([np.asarray(ctr, dtype=np.float64)[:2] for ctr, _ in obstacles], dtype=np.float64).reshape(M, 2)
+        cx[:] = cs[:, 0]
+        cy[:] = cs[:, 1]
+        if velocities is not None:
             v = np.asarray(velocities, dtype=np.float64).reshape(M, 2)
-            vx, vy = f32(v[:, 0]), f32(v[:, 1])
+            vx[:] = v[:, 0]
+            vy[:] = v[:, 1]
         self._check(self._lib.sfm_set_dynamic_obstacles(self._h, M, iptr(off), fptr(px), fptr(py), fptr(cx), fptr(cy),
-                                                        fptr(vx), fptr(vy)), "sfm_set_dynamic_obstacles")
+                                                        fptr(vx) if velocities is not None else None,
+                                                        fptr(vy) if velocities is not None else None), "sfm_set_dynamic_obstacles")
+
+    def set_dynamic_vehicles(self, positions, rings, velocities):
+        """The simulator's per-tick vehicle report (obstacles.py:297-329: centres, ring point arrays, velocities) through
+        sfm_set_dynamic_obstacles_packed: one concatenate into a kept fp32 buffer, two array writes, one call with kept addresses."""
+        M = len(rings)
+        if M == 0:
+            return self.set_dynamic_obstacles(None)
+        lens = tuple(map(len, rings))
+        c = getattr(self, "_veh_bufs", None)
+        if c is None or c[0] != lens:
+            off = np.zeros(M + 1, dtype=np.int32)
+            off[1:] = np.cumsum(lens)
+            pts, cv = np.empty((max(int(off[-1]), 1), 2), np.float32), np.zeros((M, 4), np.float32)
+            c = self._veh_bufs = (lens, off, pts, cv, off.ctypes.data, pts.ctypes.data, cv.ctypes.data)
+        _, off, pts, cv, p_off, p_pts, p_cv = c
+        if off[-1]:
+            np.concatenate(rings, axis=0, out=pts[:off[-1]], casting="same_kind")
+        cv[:, 0:2] = np.asarray(positions, dtype=np.float64).reshape(M, -1)[:, :2]
+        cv[:, 2:4] = 0.0 if velocities is None else np.asarray(velocities, dtype=np.float64).reshape(M, 2)
+        self._check(self._lib.sfm_set_dynamic_obstacles_packed(self._h, M, p_off, p_pts, p_cv), "sfm_set_dynamic_obstacles_packed")
 
     def set_dynamic_boxes(self, centers, yaws, extents, velocities, resolution=0.1):
         """Vehicles as oriented boxes (centre (M,2), yaw rad (M,), half-extents (M,2), velocity (M,2)); ring
@@ -210,8 +249,15 @@ class SfmEngine:
         float32 (N, 3).  All three C-contiguous; nothing is allocated or converted here."""
         n = rows.shape[0]
         self.planar = zvz is None
-        self._check(self._lib.sfm_step_packed(self._h, n, fptr(rows), fptr(zvz), self._flags(integrate, redraw, False), fptr(v_out)),
-                    "sfm_step_packed")
+        # (the three buffers are prefixes of arrays the caller keeps: their addresses are looked up once per array, not per tick)
+        key = (id(rows.base), id(v_out.base))
+        if getattr(self, "_step_key", None) != key:
+            self._step_key, self._step_ptrs = key, (fptr(rows), fptr(v_out))
+        p_rows, p_out = self._step_ptrs
+        rc = self._lib.sfm_step_packed(self._h, n, p_rows, None if zvz is None else fptr(zvz),
+                                       (_lib.TICK_INTEGRATE if integrate else 0) | (_lib.TICK_REDRAW_WAYPOINTS if redraw else 0), p_out)
+        if rc != 0:
+            self._check(rc, "sfm_step_packed")
         self.n = n
         self.shard = (0, n)
 

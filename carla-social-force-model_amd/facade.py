@@ -103,11 +103,15 @@ class PedestrianSimulation:
 
     # ---- device synchronisation ---------------------------------------------------------------------------
     def _stage(self, force_name, **kw):
-        self._staged.setdefault(force_name, {}).update(kw)
+        d = self._staged.setdefault(force_name, {})
+        d.pop('vehicles', None)              # an explicit update_obstacles / update_obstacle_velocities overrides the tick's vehicle report
+        d.update(kw)
 
     def _sync_device(self, peds):
         for name, what in self._staged.items():
-            if name == 'dynamic_obstacle_force':
+            if name == 'dynamic_obstacle_force' and 'vehicles' in what:
+                self.engine.set_dynamic_vehicles(*what['vehicles'])
+            elif name == 'dynamic_obstacle_force':
                 self.engine.set_dynamic_obstacles(what.get('obstacles', self.dyn_obstacles), what.get('velocities'))
             elif name == 'static_obstacle_force' and 'obstacles' in what:
                 self.engine.set_static_obstacles(what['obstacles'])
@@ -124,7 +128,9 @@ class PedestrianSimulation:
         """pedestrian_simulation.py:81-83 on the GPU, host record array in, v' out: staged geometry updates, then ONE library call
         (sfm_step_packed) on one packed fp32 block written straight out of the 132-byte records."""
         for name, what in self._staged.items():
-            if name == 'dynamic_obstacle_force':
+            if name == 'dynamic_obstacle_force' and 'vehicles' in what:
+                self.engine.set_dynamic_vehicles(*what['vehicles'])
+            elif name == 'dynamic_obstacle_force':
                 self.engine.set_dynamic_obstacles(what.get('obstacles', self.dyn_obstacles), what.get('velocities'))
             elif name == 'static_obstacle_force' and 'obstacles' in what:
                 self.engine.set_static_obstacles(what['obstacles'])
@@ -225,8 +231,8 @@ class PedestrianSimulation:
         self.dyn_obstacles = list(zip(positions, rings))
         moving = self.forces.get('dynamic_obstacle_force')
         if moving is not None and self.dyn_obstacles:
-            moving.update_obstacles(self.dyn_obstacles)
-            moving.update_obstacle_velocities(velocities)
+            # (staged like ObstacleForce.update_obstacles / update_obstacle_velocities, forces.py:285-291, but as the arrays they came in)
+            self._staged['dynamic_obstacle_force'] = {'vehicles': (positions, rings, velocities)}
 
     def record_dyn_obstacle_states(self, sim_time):
         rec = np.empty(len(self.dyn_obs_ids), dtype=VEHICLE_RECORD)

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SFM_ABI_VERSION 4   /* 2: + sfm_tick_begin / sfm_tick_end, sfm_set_partition, sfm_get_pair_work; 3: + sfm_set_timing; 4: + sfm_step_packed (additions only) */
+#define SFM_ABI_VERSION 4   /* 2: + sfm_tick_begin / sfm_tick_end, sfm_set_partition, sfm_get_pair_work; 3: + sfm_set_timing; 4: + sfm_step_packed, sfm_set_dynamic_obstacles_packed (additions only) */
 
 typedef struct SfmHandle SfmHandle;
 
@@ -91,6 +91,9 @@ int sfm_set_static_obstacles(SfmHandle* h, int M, const int32_t* offsets, const 
  * (pedestrian_simulation.py:108-115; forces.py:285-291). */
 int sfm_set_dynamic_obstacles(SfmHandle* h, int M, const int32_t* offsets, const float* px, const float* py,
                               const float* cx, const float* cy, const float* vx, const float* vy);
+/* The same from packed arrays (ABI 4): pts [P][2] {x, y}, cv [M][4] {cx, cy, vx, vy}; replaces the same two reference calls
+ * (forces.py:285-291) for a caller that is handed the vehicles every tick (run_simulation.py:95, obstacles.py:297-329). */
+int sfm_set_dynamic_obstacles_packed(SfmHandle* h, int M, const int32_t* offsets, const float* pts, const float* cv);
 
 /* Device-side form of get_dynamic_obstacles (obstacles.py:297-329) for CARLA-free runs:
  * the vehicles are given once as oriented boxes -- ring-local offsets (the ellipse of obstacles.py:269-281 before
