@@ -295,6 +295,8 @@ def main():
     st.exchange()                 # brings the communicator up outside the timed region (idempotent on a fresh state)
     eng.engine.set_timing(False)  # the library's own HIP-event bracket of every call (sfm_get_timing) stays out of the timed windows:
     st.step(args.warmup)          # two event records per call, ~11 us -- 3 % of a 20-tick window of c2
+    if world > 1 and st.split_mode == "auto":
+        st.step(24)               # (a short warm-up: let the stepper finish choosing between the split and the plain tick)
     times = timed_windows(st.step, barrier, reduce_max, args.steps, args.windows, args.min_seconds)
     elapsed = statistics.median(times)
 
@@ -429,6 +431,8 @@ def main():
             ops = 65.0 * n * (n - 1.0) * ticks_s
             out["roofline"]["valu_algorithmic"] = {"ops_per_ordered_pair": 65.0, "achieved_ops_per_s": ops, "peak_ops_per_s": 7.9e13,
                                                    "frac": ops / 7.9e13 / world}
+        if world > 1:
+            out["config"]["tick_form"] = getattr(st, "split_probe", {"chosen": "split" if st.split_mode else "plain"})
         if single_ref is not None:
             single_ref["speedup"] = ticks_s / single_ref["value"]
             out["single_gpu_same_workload"] = single_ref

@@ -98,6 +98,20 @@ struct SfmHandle {
     float* slabz = nullptr;                // 3-D crowds: the z components (same indexing)
     int n_t = 0;
     size_t slab_cap = 0, slabz_cap = 0;
+    // list mode (round 4): row pairs of the pool instead of the dense slab -- O(kept tile pairs) instead of O(N^2 / 64)
+    float2* pool = nullptr;                // [2 * pool_pairs][64]
+    float* poolz = nullptr;
+    size_t pool_pairs = 0, poolz_pairs = 0;
+    uint32_t pool_main = 0;                // row pairs of the main list; the split tick's own-own list owns the ones behind
+    bool pooled = false;                   // this tick's list-mode launches use the pool (else the dense slab)
+    uint32_t* pair_idx = nullptr;          // [own tiles][n_t] -> row pair (SymArgs::idx)
+    size_t pair_idx_cap = 0;
+    long long* ovf = nullptr;              // [4][N_pad] overflow sums (pairs beyond the pool's capacity)
+    size_t ovf_cap = 0;
+    SpillArgs* spill = nullptr;            // device twin of {ovf, N_pad, serial of the last spilling tick}
+    long long* spill_ovf = nullptr;        // what the device twin holds
+    int spill_n_pad = 0;
+    int tick_serial = 0;
     int dpp_dir = 0;
     int sym_mode = -1;                     // SFM_SYM: 0 off, 1 on when eligible, -1 auto
     // tile-granular cutoff of provably negligible pedestrian pairs
@@ -450,6 +464,11 @@ int sfm_destroy(SfmHandle* h) {
     if (h->dyn_rot) hipFree(h->dyn_rot);
     if (h->slab) hipFree(h->slab);
     if (h->slabz) hipFree(h->slabz);
+    if (h->pool) hipFree(h->pool);
+    if (h->poolz) hipFree(h->poolz);
+    if (h->pair_idx) hipFree(h->pair_idx);
+    if (h->ovf) hipFree(h->ovf);
+    if (h->spill) hipFree(h->spill);
     if (h->fslab) hipFree(h->fslab);
     if (h->fgeo) hipFree(h->fgeo);
     if (h->fslabz) hipFree(h->fslabz);
@@ -841,13 +860,9 @@ int sfm_upload_state(SfmHandle* h, int N, const float* x, const float* y, const 
     }
     h->ticks_since_sort = 0;
     h->perm_stale = false;
-    // slab of the symmetric path: n_t x (n_t*64) float2 (8.6 GB at N = 262 144), up to 16 GiB of the 288 GB
+    // (the symmetric path's partial forces -- dense slab without the list cutoff, row pool with it -- are reserved by the first tick
+    //  that needs them: sym_reserve)
     h->n_t = (N + WAVE - 1) / WAVE;
-    const size_t need = (size_t)h->n_t * (size_t)slab_stride(h->n_t);
-    if (h->dpp_dir == 1 && h->sym_mode != 0 && need * sizeof(float2) <= ((size_t)16 << 30)) {
-        if (need > h->slab_cap) { HIP_TRY(h, dev_realloc(h->slab, need)); h->slab_cap = need; }
-        if (z3 && need > h->slabz_cap) { HIP_TRY(h, dev_realloc(h->slabz, need)); h->slabz_cap = need; }
-    }
     // cutoff bookkeeping: per-tile box / max speed, and the work list of the symmetric kernel
     h->r_max = 0.f;
     if (rad) for (int i = 0; i < N; ++i) h->r_max = std::fmax(h->r_max, radius[i]);
@@ -1016,7 +1031,8 @@ static void fill_args(SfmHandle* h, TickArgs& a, uint32_t flags) {
     // device-side vehicles move on at the end of an integrating tick: extra workgroups of the tick's last kernel
     a.adv = DynAdvance{h->dynamics.ctr, h->dynamics.off, h->dyn_local, h->dyn_rot, h->dynamics.pts,
                        (h->dyn_boxes && (flags & SFM_TICK_INTEGRATE)) ? h->dynamics.K : 0, h->prm.step_length, 0};
-    const bool cut = p.enabled[SFM_FORCE_PEDESTRIAN] && h->tile_box && h->N <= 64 * 64 * WAVE &&
+    // (up to 4096 tiles the ordered kernel can use the boxes too; beyond, only the symmetric path's list does -- items carry 15-bit shifts)
+    const bool cut = p.enabled[SFM_FORCE_PEDESTRIAN] && h->tile_box && (h->N <= 64 * 64 * WAVE || (h->dpp_dir == 1 && h->sym_mode != 0 && h->n_t < 32768)) &&
                      (h->cut_mode == 1 || (h->cut_mode < 0 && h->N > AUTO_CUTOFF_N)) && p.pedestrian.gamma > 0.f && p.pedestrian.lambda >= 0.f;
     a.tile_box = cut ? h->tile_box + (size_t)h->box_cur * h->n_t : nullptr;
     a.tile_vmax = cut ? h->tile_vmax + (size_t)h->box_cur * h->n_t : nullptr;
@@ -1025,7 +1041,7 @@ static void fill_args(SfmHandle* h, TickArgs& a, uint32_t flags) {
     // into every test -- and a 3-D crowd's largest speed includes v_z)
     // (a cutoff for small crowds -- workgroups testing their own tile pair, a cost-balanced deal of the items -- was built and
     //  measured in round 2: on c2 it cost as much in boxes, dealer and re-packs as it saved in steps.  Removed in round 3)
-    const bool carry = cut && h->slab && h->i_begin == 0 && h->i_end == h->N && h->sym_mode != 0 && h->carry_mode != 0 && !h->fsm_on;
+    const bool carry = cut && h->dpp_dir == 1 && h->i_begin == 0 && h->i_end == h->N && h->sym_mode != 0 && h->carry_mode != 0 && !h->fsm_on;
     a.tile_box_out = carry ? h->tile_box + (size_t)(h->box_cur ^ 1) * h->n_t : nullptr;
     a.tile_vmax_out = carry ? h->tile_vmax + (size_t)(h->box_cur ^ 1) * h->n_t : nullptr;
     a.cut_scale = (float)((double)p.pedestrian.gamma * 41.0 * 0.6931471805599453 * 1.001);
@@ -1097,14 +1113,70 @@ static void strip_shape(const SfmHandle* h, int* tps, int* n_strips) {
     *n_strips = on ? (h->n_t + *tps - 1) / *tps : 0;
 }
 
-// the symmetric path's view of one tick: slab, tile-pair list (cutoff on), strips, own tile range
+// Memory of the symmetric path's partial forces for the shape the next tick has.  Without the tile-pair list (grid mode: crowds up to
+// ~8000 pedestrians, or SFM_CUTOFF=0) the dense slab n_t x (n_t * 64) float2, up to 16 GiB.  With the list (round 4) a pool of row pairs:
+// 80 per own tile of a whole crowd (c5 keeps 43), 144 per own tile of a shard (pairs with other ranks' tiles are listed one-sided by
+// both ranks), never more than every pair there is; the split tick's own-own list gets as many again behind them.  c5: 0.34 GB instead
+// of 8.6.  More kept pairs than that (tiles that overlap: a crowd uploaded in random order with SFM_REORDER=0) spill into the overflow
+// sums -- slower, never wrong.  false: does not fit (the caller falls back to the ordered kernel).
+static bool sym_reserve(SfmHandle* h, bool list, bool split) {
+    // The pool costs the epilogue one more dependent load per partner tile (the row's index) and the list kernels a scattered store per
+    // item: c3 +5 %, c4 +2.5 %, c5 +2 % per tick against the dense slab (profiles/r04_row_pool_ab.txt).  So the dense slab stays while it
+    // is small -- up to 1 GiB: crowds of up to ~90 000 pedestrians, c3 (0.27 GB) and c4 (0.54 GB) among them -- and the pool takes over
+    // where the slab is what limits the crowd (c5: 8.6 GB -> 0.34 GB; N = 524 288: 34 GB -> 0.7 GB).  SFM_POOL=0 / 1 forces either.
+    static const int pool_ov = getenv("SFM_POOL") ? atoi(getenv("SFM_POOL")) : -1;
+    const size_t dense = (size_t)h->n_t * (size_t)slab_stride(h->n_t);
+    h->pooled = list && (pool_ov >= 0 ? pool_ov != 0 : dense * sizeof(float2) > ((size_t)1 << 30));
+    if (!h->pooled) {
+        const size_t need = dense;
+        if (need * sizeof(float2) > ((size_t)16 << 30)) return false;
+        if (need > h->slab_cap) { if (dev_realloc(h->slab, need) != hipSuccess) return false; h->slab_cap = need; }
+        if (h->z3 && need > h->slabz_cap) { if (dev_realloc(h->slabz, need) != hipSuccess) return false; h->slabz_cap = need; }
+        return true;
+    }
+    const size_t own = (size_t)((h->i_end + WAVE - 1) / WAVE - h->i_begin / WAVE), n_t = (size_t)h->n_t;
+    const bool whole = h->i_begin == 0 && h->i_end == h->N;
+    const size_t every = whole ? n_t * (n_t / 2 + 1) : own * n_t;
+    static const long per_ov = getenv("SFM_POOL_PER_TILE") ? atol(getenv("SFM_POOL_PER_TILE")) : 0;   // tests: a small pool makes pairs spill
+    const size_t per_tile = per_ov > 0 ? (size_t)per_ov : (whole ? 80 : 144);
+    const size_t main_pairs = std::min(every, std::max<size_t>(per_ov > 0 ? 1 : 4096, own * per_tile));
+    const size_t pairs = main_pairs * (split ? 2 : 1);
+    if (pairs * 2 * WAVE * sizeof(float2) > ((size_t)16 << 30)) return false;
+    if (pairs > h->pool_pairs) { if (dev_realloc(h->pool, pairs * 2 * WAVE) != hipSuccess) return false; h->pool_pairs = pairs; }
+    if (h->z3 && pairs > h->poolz_pairs) { if (dev_realloc(h->poolz, pairs * 2 * WAVE) != hipSuccess) return false; h->poolz_pairs = pairs; }
+    h->pool_main = (uint32_t)main_pairs;
+    if (own * n_t > h->pair_idx_cap) { if (dev_realloc(h->pair_idx, own * n_t) != hipSuccess) return false; h->pair_idx_cap = own * n_t; }
+    const size_t no = (size_t)4 * (size_t)h->N_pad;
+    if (no > h->ovf_cap) {
+        if (dev_realloc(h->ovf, no) != hipSuccess) return false;
+        h->ovf_cap = no;
+        if (hipMemsetAsync(h->ovf, 0, sizeof(long long) * no, h->stream) != hipSuccess) return false;
+    }
+    if (!h->spill && dev_realloc(h->spill, (size_t)1) != hipSuccess) return false;
+    if (h->spill_ovf != h->ovf || h->spill_n_pad != h->N_pad) {        // (once per upload that changes them; a pageable 24-byte copy)
+        const SpillArgs sp{h->ovf, h->N_pad, 0};
+        if (hipMemcpyAsync(h->spill, &sp, sizeof(sp), hipMemcpyHostToDevice, h->stream) != hipSuccess) return false;
+        if (hipStreamSynchronize(h->stream) != hipSuccess) return false;
+        h->spill_ovf = h->ovf; h->spill_n_pad = h->N_pad;
+    }
+    return true;
+}
+
+// the symmetric path's view of one tick: slab or row pool, tile-pair list (cutoff on), strips, own tile range
 static SymArgs make_sym_args(const SfmHandle* h, const TickArgs& a, int tps, int n_strips, int debug_steps, unsigned long long* stamps) {
     const bool list = a.tile_box != nullptr;
-    return SymArgs{h->slab, h->z3 ? h->slabz : nullptr, h->n_t, slab_stride(h->n_t), debug_steps,
-                   list ? h->work : nullptr, list ? h->work_count : nullptr, list ? a.tile_vmax : nullptr,
-                   a.cut_scale, a.cut_pad, stamps, h->strip_box, h->strip_vmax, tps, n_strips,
-                   h->i_begin / WAVE, (h->i_end + WAVE - 1) / WAVE,
-                   (list && a.tile_box_out) ? 1 : 0};      // (shards: run_ticks sets it, it knows whether the tick integrates)
+    SymArgs sa{h->slab, h->z3 ? h->slabz : nullptr, h->n_t, slab_stride(h->n_t), debug_steps,
+               list ? h->work : nullptr, list ? h->work_count : nullptr, list ? a.tile_vmax : nullptr,
+               a.cut_scale, a.cut_pad, stamps, h->strip_box, h->strip_vmax, tps, n_strips,
+               h->i_begin / WAVE, (h->i_end + WAVE - 1) / WAVE,
+               (list && a.tile_box_out) ? 1 : 0,      // (shards: run_ticks sets it, it knows whether the tick integrates)
+               nullptr, 0u, 0u, nullptr, h->tick_serial};
+    if (list && h->pooled) {
+        sa.slab = h->pool; sa.slabz = h->z3 ? h->poolz : nullptr; sa.idx = h->pair_idx;
+        sa.row_base = 0u; sa.cap_pairs = h->pool_main;
+        sa.spill = h->spill;
+    }
+    return sa;
 }
 
 constexpr int PHASE_FULL = 0, PHASE_BEGIN = 1, PHASE_END = 2;
@@ -1244,7 +1316,6 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags, int phase = PHASE_
     int tps = 1, n_strips = 0;
     strip_shape(h, &tps, &n_strips);
     // symmetric path: planar crowd, the whole of it on this handle or a tile-aligned shard; auto mode wants >= 4 tiles
-    const size_t need = (size_t)h->n_t * (size_t)slab_stride(h->n_t);
     bool order_pays, list_cut, plain, fused_geo;    // compact tiles only matter to the tile cutoff and the geometry kernel
     {
         TickArgs probe;
@@ -1259,8 +1330,9 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags, int phase = PHASE_
     const bool whole = h->i_begin == 0 && h->i_end == h->N;
     const bool tile_shard = n_local > 0 && (h->i_begin % WAVE) == 0 && ((h->i_end % WAVE) == 0 || h->i_end == h->N) && list_cut &&
                             h->n_t < 32768;
-    const bool sym_any_size = (whole || tile_shard) && h->slab && need <= h->slab_cap && (!h->z3 || (h->slabz && need <= h->slabz_cap)) &&
-                              h->dpp_dir == 1 && h->prm.enabled[SFM_FORCE_PEDESTRIAN];
+    const bool sym_wanted = (whole || tile_shard) && h->dpp_dir == 1 && h->sym_mode != 0 && h->prm.enabled[SFM_FORCE_PEDESTRIAN] &&
+                            (h->sym_mode == 1 || h->N >= 256 || device_run || carry);
+    const bool sym_any_size = sym_wanted && sym_reserve(h, list_cut, !whole && h->split_mode != 0);
     // ---- a device-resident run of a whole crowd below the list cutoff: one launch per tick (sfm_fused_tick_kernel).
     //      Every sfm_run / sfm_run_recorded takes it, whatever its length -- what a device-resident run computes must not depend on
     //      how the caller cuts it into calls (a lone sfm_run(1) pays a launch in front like the two-launch tick pays its epilogue) --
@@ -1287,6 +1359,7 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags, int phase = PHASE_
         if (items > h->work2_cap) { HIP_TRY(h, dev_realloc(h->work2, items)); h->work2_cap = items; }
         if (h->timing_on) HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
         ++h->ticks_since_sort;
+        ++h->tick_serial;                              // (the two halves of a split tick share it: overflow sums of both lists)
         TickArgs a;
         fill_args(h, a, flags);
         const int t_lo = h->i_begin / WAVE, t_hi = (h->i_end + WAVE - 1) / WAVE;
@@ -1308,6 +1381,7 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags, int phase = PHASE_
         SymArgs sa = make_sym_args(h, a, tps, 0, h->debug_steps, nullptr);
         sa.work = h->work2;
         sa.work_count = h->work_count + 1;
+        sa.row_base = h->pool_main;                       // the own-own list's row pairs sit behind the main list's
         HIP_TRY(h, launch_sym_list(a, sa, h->stream, LIST_OWN, h->count_zeroed));
         if (merged) {
             a.geo_slices = merged_geo_slices(t_hi - t_lo, a.geo_slices);
@@ -1334,7 +1408,7 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags, int phase = PHASE_
             if (rc) return rc;
             launches += 5;
         }
-        if (!finishing) ++h->ticks_since_sort;
+        if (!finishing) { ++h->ticks_since_sort; ++h->tick_serial; }
         bool shard_zeroed = false;
         TickArgs a;
         fill_args(h, a, flags);
@@ -1400,7 +1474,7 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags, int phase = PHASE_
             // workgroups of this launch instead of a launch of its own between the geometry and the pair kernel (c3: 4 -> 3 launches)
             list_in_geo = sym && whole && carried && h->count_zeroed && list_cut && n_strips == 0 && !finishing && a.en_ped &&
                           h->N > 1 && h->list_merge_mode != 0;
-            if (list_in_geo) { a.list_work = h->work; a.list_count = h->work_count; a.list_n_t = h->n_t; }
+            if (list_in_geo) { a.list_work = h->work; a.list_count = h->work_count; a.list_n_t = h->n_t; a.list_idx = h->pooled ? h->pair_idx : nullptr; a.list_cap = h->pool_main; }
             HIP_TRY(h, launch_geometry(h->rad, a, h->stream));
             ++launches;
         }

@@ -114,6 +114,8 @@ struct TickArgs {
     uint32_t* list_work;
     int* list_count;
     int list_n_t, list_block0;
+    uint32_t* list_idx;       // ... and the pool's index table (SymArgs::idx), null: dense slab
+    uint32_t list_cap;        // ... and its capacity in row pairs
     unsigned long long* geo_stamps;   // diagnostic runs only (SFM_GEO_STAMPS): per geometry workgroup {start, after find, after scan, end} of s_memrealtime
 };
 
@@ -139,6 +141,25 @@ struct SymArgs {
     int t_lo, t_hi;      // tiles of this handle's rows (a shard; whole crowd: 0, n_t).  Pairs with a tile outside are
                          // evaluated one-sided: the other side belongs to another rank, which evaluates it itself
     int zero_count;      // epilogue launch: 1 = leave *work_count at 0 for the next tick's list kernel (saves its memset)
+    // Round 4 -- list mode can keep its partial forces in a POOL of row pairs instead of the dense slab (8.6 GB at N = 262 144:
+    // O(N^2 / 64); the pool is O(kept tile pairs)).  idx != null: `slab` / `slabz` ARE the pool, [2 * pairs][64]: list item p of this
+    // launch owns row pair q = row_base + p -- row 2q the force on the travelling tile's pedestrians (a diagonal item: on tile bx's),
+    // row 2q + 1 on the resident tile's (tile bx + half_up's) -- and the list kernels leave q in idx[(bx - t_lo) * n_t + shift], where
+    // the epilogue looks it up for the partner tiles its predicate keeps.  An item beyond the list's share of the pool (p >= cap_pairs: a
+    // crowd whose tiles overlap keeps everything) adds its sums to spill->ovf in 2^-36 fixed point by integer atomics -- exact,
+    // order-independent, hence still deterministic -- and stamps spill->tick.  (Few fields on purpose: every one is two more SGPRs in
+    // kernels that sit at the occupancy limit.)
+    uint32_t* idx;       // [t_hi - t_lo][n_t]; null: dense slab
+    uint32_t row_base;   // first row pair of this launch's list (the split tick's own-own list sits behind the main one)
+    uint32_t cap_pairs;  // row pairs a list may use; item positions beyond spill
+    struct SpillArgs* spill;
+    int tick_serial;     // of the tick being computed (the two halves of a split tick share it)
+};
+
+struct SpillArgs {       // (device memory; read only by an item that spills and by the epilogue)
+    long long* ovf;      // [4][N_pad]: x, y, z sums in 2^-36 fixed point, count of non-finite sums
+    int n_pad;
+    int tick;            // serial of the last tick in which an item spilled
 };
 
 // Fused tick of a whole planar crowd with the acceleration and pedestrian forces only (sfm_fused_tick_kernel):

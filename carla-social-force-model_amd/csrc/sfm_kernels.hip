@@ -662,7 +662,14 @@ __device__ __forceinline__ bool list_candidate(const float4* __restrict__ box, c
 // on it takes ~11 ns whatever else goes on, and a wave-level append (what `work[atomicAdd(count, 1)]` compiles to) made those
 // atomics the flat list kernel's whole duration (c4: ~800 waves with an item, 10 us).  Every thread of the workgroup must call it.
 // s_n: [waves + 1] ints of LDS.
-__device__ __forceinline__ void list_emit(bool keep, uint32_t item, uint32_t* __restrict__ work, int* __restrict__ count, int* s_n) {
+// where the list kernels leave an item's row pair for the epilogue (SymArgs::idx): item = bx | shift << 16 [| one-sided]
+// (position `pos` of the launch's list, `cap` row pairs per list; beyond: 0xffffffff = the pair spills into the overflow sums)
+__device__ __forceinline__ void list_index(uint32_t* __restrict__ idx, int n_t, int t_lo, uint32_t item, uint32_t row_base, uint32_t pos, uint32_t cap) {
+    if (idx) idx[(size_t)((int)(item & 0xffffu) - t_lo) * (size_t)n_t + ((item >> 16) & 0x7fffu)] = pos < cap ? row_base + pos : 0xffffffffu;
+}
+
+__device__ __forceinline__ void list_emit(bool keep, uint32_t item, uint32_t* __restrict__ work, int* __restrict__ count, int* s_n,
+                                          uint32_t* __restrict__ idx = nullptr, int n_t = 0, int t_lo = 0, uint32_t row_base = 0u, uint32_t cap = 0u) {
     const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6, waves = (blockDim.x + WAVE - 1) >> 6;
     const unsigned long long m = __ballot(keep);
     if (lane == 0) s_n[wave] = __popcll(m);
@@ -674,7 +681,11 @@ __device__ __forceinline__ void list_emit(bool keep, uint32_t item, uint32_t* __
         for (int w = 0; w < waves; ++w) s_n[w] += base;
     }
     __syncthreads();
-    if (keep) work[s_n[wave] + __popcll(m & ((1ull << lane) - 1ull))] = item;
+    if (keep) {
+        const int pos = s_n[wave] + __popcll(m & ((1ull << lane) - 1ull));
+        work[pos] = item;
+        list_index(idx, n_t, t_lo, item, row_base, (uint32_t)pos, cap);
+    }
 }
 
 #ifndef GEO_DIRECT_PER_WAVE
@@ -813,7 +824,7 @@ __global__ __launch_bounds__(GW * WAVE, 8) void sfm_geometry_kernel(const TickAr
             const bool keep = shift <= (a.list_n_t >> 1) &&
                               list_candidate(a.tile_box, a.tile_vmax, a.list_n_t, 0, a.list_n_t, a.ped.lam, a.cut_scale, a.cut_pad,
                                              PARTNERS_ALL, idx - shift * a.list_n_t, shift, item);
-            list_emit(keep, item, a.list_work, a.list_count, s_n);
+            list_emit(keep, item, a.list_work, a.list_count, s_n, a.list_idx, a.list_n_t, 0, 0u, a.list_cap);
         }
         return;
     }
@@ -1383,12 +1394,13 @@ __global__ __launch_bounds__(TSB_WAVES * WAVE) void sfm_tile_strip_bounds_kernel
 
 __global__ __launch_bounds__(256) void sfm_pair_list_kernel(const float4* __restrict__ box, const float* __restrict__ vmax, int n_t, int t_lo,
                                                             int t_hi, float lam, float cut_scale, float cut_pad,
-                                                            uint32_t* __restrict__ work, int* __restrict__ count, int partners) {
+                                                            uint32_t* __restrict__ work, int* __restrict__ count, int partners,
+                                                            uint32_t* __restrict__ idx, uint32_t row_base, uint32_t cap) {
     __shared__ int s_n[5];
     uint32_t item = 0u;
     const bool keep = list_candidate(box, vmax, n_t, t_lo, t_hi, lam, cut_scale, cut_pad, partners,
                                      t_lo + (int)(blockIdx.x * blockDim.x + threadIdx.x), (int)blockIdx.y, item);
-    list_emit(keep, item, work, count, s_n);
+    list_emit(keep, item, work, count, s_n, idx, n_t, t_lo, row_base, cap);
 }
 
 // The same list for large crowds, two levels: one wave per own tile tests the strips first, 64 at a time (a strip's box
@@ -1415,7 +1427,7 @@ __global__ __launch_bounds__(LIST2_WAVES * WAVE) void sfm_pair_list2_kernel(cons
         int base = 0;
         if (lane == 0) base = atomicAdd(count, n_buf);
         base = __builtin_amdgcn_readfirstlane(base);
-        for (int q = lane; q < n_buf; q += WAVE) work[base + q] = buf[q];
+        for (int q = lane; q < n_buf; q += WAVE) { work[base + q] = buf[q]; list_index(sa.idx, sa.n_t, sa.t_lo, buf[q], sa.row_base, (uint32_t)(base + q), sa.cap_pairs); }
         n_buf = 0;
     };
     const int n_t = sa.n_t;
@@ -1491,7 +1503,7 @@ __global__ __launch_bounds__(LIST2_WAVES * WAVE) void sfm_pair_list2_kernel(cons
     __syncthreads();
     int base = s_base;
     for (int w = 0; w < wave; ++w) base += s_n[w];
-    for (int q = lane; q < n_buf; q += WAVE) work[base + q] = buf[q];
+    for (int q = lane; q < n_buf; q += WAVE) { work[base + q] = buf[q]; list_index(sa.idx, sa.n_t, sa.t_lo, buf[q], sa.row_base, (uint32_t)(base + q), sa.cap_pairs); }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1678,6 +1690,34 @@ __device__ __forceinline__ void pair_block(const float4* __restrict__ pk, const 
     sh.fj[wave][lane] = make_float2(fxj, fyj);
     if (Z3) { sh.fiz[wave][i_end_loc] = fzi; sh.fjz[wave][lane] = fzj; }
     __syncthreads();
+    // Where the two rows of this item go: the dense slab (grid mode), or -- list mode, round 4 -- row pair q of the pool; a pair
+    // beyond the pool's capacity adds its sums to the overflow accumulators instead (integer atomics: order-independent).
+    const bool pooled = sa.idx != nullptr;
+    const bool spill = pooled && (uint32_t)item >= sa.cap_pairs;
+    auto put = [&](int side, int t_of, int t_from, int p, float vx_, float vy_, float vz_) {   // force on pedestrian p of tile t_of from tile t_from
+        if (spill) {
+            SpillArgs* sp = sa.spill;
+            const size_t np_ = (size_t)sp->n_pad;
+            const size_t i_ = (size_t)t_of * WAVE + p;
+            constexpr float S = 68719476736.0f;                        // 2^36
+            const bool fin = fabsf(vx_) < __builtin_inff() && fabsf(vy_) < __builtin_inff() && (!Z3 || fabsf(vz_) < __builtin_inff());
+            unsigned long long* ov = reinterpret_cast<unsigned long long*>(sp->ovf);
+            if (fin) {
+                atomicAdd(ov + i_, (unsigned long long)__float2ll_rn(vx_ * S));
+                atomicAdd(ov + np_ + i_, (unsigned long long)__float2ll_rn(vy_ * S));
+                if (Z3) atomicAdd(ov + 2 * np_ + i_, (unsigned long long)__float2ll_rn(vz_ * S));
+            } else {
+                atomicAdd(ov + 3 * np_ + i_, 1ull);                    // a coincident pair's NaN: the epilogue recomputes the tile exactly
+            }
+            sp->tick = sa.tick_serial;
+        } else {
+            // row pair q = row_base + item of the pool, or the dense slab's (partner tile, pedestrian) entry
+            const size_t r = pooled ? ((size_t)2 * (sa.row_base + (uint32_t)item) + (size_t)side) * WAVE + p
+                                    : (size_t)t_from * sa.stride + t_of * WAVE + p;
+            sa.slab[r] = make_float2(vx_, vy_);
+            if (Z3) sa.slabz[r] = vz_;
+        }
+    };
     if (shift == 0) {
         // waves 0,1 -> tile bx ; waves 2,3 -> tile bx + half_up
         if (tid < 2 * WAVE) {
@@ -1686,21 +1726,20 @@ __device__ __forceinline__ void pair_block(const float4* __restrict__ pk, const 
             if (t < sa.t_hi) {
                 const int p = tid & (WAVE - 1);
                 const float2 a0 = sh.fi[2 * g][p], a1 = sh.fi[2 * g + 1][p], b0 = sh.fj[2 * g][p], b1 = sh.fj[2 * g + 1][p];
-                sa.slab[(size_t)t * sa.stride + t * WAVE + p] = make_float2(((a0.x + a1.x) + b0.x) + b1.x,
-                                                                            ((a0.y + a1.y) + b0.y) + b1.y);
-                if (Z3) sa.slabz[(size_t)t * sa.stride + t * WAVE + p] = ((sh.fiz[2 * g][p] + sh.fiz[2 * g + 1][p]) + sh.fjz[2 * g][p]) + sh.fjz[2 * g + 1][p];
+                put(g, t, t, p, ((a0.x + a1.x) + b0.x) + b1.x, ((a0.y + a1.y) + b0.y) + b1.y,
+                    Z3 ? ((sh.fiz[2 * g][p] + sh.fiz[2 * g + 1][p]) + sh.fjz[2 * g][p]) + sh.fjz[2 * g + 1][p] : 0.f);
             }
         }
     } else if (tid < 2 * WAVE) {
         const int p = tid & (WAVE - 1);
         if (tid < WAVE) {     // force on tile ta's pedestrians from tile tb
             const float2 a0 = sh.fi[0][p], a1 = sh.fi[1][p], a2 = sh.fi[2][p], a3 = sh.fi[3][p];
-            sa.slab[(size_t)tb * sa.stride + ta * WAVE + p] = make_float2(((a0.x + a1.x) + a2.x) + a3.x, ((a0.y + a1.y) + a2.y) + a3.y);
-            if (Z3) sa.slabz[(size_t)tb * sa.stride + ta * WAVE + p] = ((sh.fiz[0][p] + sh.fiz[1][p]) + sh.fiz[2][p]) + sh.fiz[3][p];
+            put(0, ta, tb, p, ((a0.x + a1.x) + a2.x) + a3.x, ((a0.y + a1.y) + a2.y) + a3.y,
+                Z3 ? ((sh.fiz[0][p] + sh.fiz[1][p]) + sh.fiz[2][p]) + sh.fiz[3][p] : 0.f);
         } else if (!one_sided) {   // force on tile tb's pedestrians from tile ta
             const float2 a0 = sh.fj[0][p], a1 = sh.fj[1][p], a2 = sh.fj[2][p], a3 = sh.fj[3][p];
-            sa.slab[(size_t)ta * sa.stride + tb * WAVE + p] = make_float2(((a0.x + a1.x) + a2.x) + a3.x, ((a0.y + a1.y) + a2.y) + a3.y);
-            if (Z3) sa.slabz[(size_t)ta * sa.stride + tb * WAVE + p] = ((sh.fjz[0][p] + sh.fjz[1][p]) + sh.fjz[2][p]) + sh.fjz[3][p];
+            put(1, tb, ta, p, ((a0.x + a1.x) + a2.x) + a3.x, ((a0.y + a1.y) + a2.y) + a3.y,
+                Z3 ? ((sh.fjz[0][p] + sh.fjz[1][p]) + sh.fjz[2][p]) + sh.fjz[3][p] : 0.f);
         }
     }
     if (sa.work) __syncthreads();                 // LDS is reused by the next item
@@ -1754,6 +1793,29 @@ __global__ __launch_bounds__(BLOCK) void sfm_pair_geo_kernel(const TickArgs a, c
     }
 }
 
+// List mode (round 4): the pool row that holds the force on tile t's pedestrians from tile u -- the same canonical form as the list
+// kernels' items (list_candidate): an own-own pair is listed once, by the tile from which the other is at most n_t / 2 ahead (the
+// antipodal tie goes to the lower half); a pair with another rank's tile by the own tile; a tile's own pairs by the diagonal item
+// it shares with tile + half_up.  An entry of 0xffffffff: the pair went to the overflow accumulators.
+__device__ __forceinline__ size_t pool_slot(const SymArgs& sa, int t, int u, uint32_t& side) {   // where the pair's entry of idx[] is
+    const int n_t = sa.n_t;
+    int owner = t, shift = 0;
+    side = 0u;
+    if (u == t) {
+        const int half_up = (sa.t_hi - sa.t_lo + 1) >> 1;
+        if (t - sa.t_lo >= half_up) { owner = t - half_up; side = 1u; }
+    } else {
+        int s_ = u - t;
+        if (s_ < 0) s_ += n_t;
+        shift = s_;
+        if (u >= sa.t_lo && u < sa.t_hi) {
+            const int s2 = n_t - s_;
+            if (s2 < s_ || (s2 == s_ && t >= (n_t >> 1))) { owner = u; shift = s2; side = 1u; }
+        }
+    }
+    return (size_t)(owner - sa.t_lo) * (size_t)n_t + shift;
+}
+
 constexpr int EPI_WAVES = 16;
 #ifndef EPI_INFLIGHT
 #define EPI_INFLIGHT 8                     // slab-row loads a wave keeps in flight under a cutoff (a multiple of 4; the sum's association follows it)
@@ -1767,7 +1829,7 @@ __global__ __launch_bounds__(EW * WAVE) void sfm_sym_epilogue_kernel(const TickA
     __shared__ float s_exactz[WAVE];
     __shared__ int s_bad[EW];
     __shared__ uint16_t s_own[EW][4096 / EW];   // two-level cutoff: the strips a wave sums (n_strips <= n_t <= 4096 under a cutoff)
-    __shared__ uint16_t s_kept[EW][4 * WAVE];   // ... and the kept tiles of four of them
+    __shared__ uint32_t s_kept[EW][4 * WAVE];   // ... and the kept tiles of four of them (list mode with the row pool: their rows)
     const int tid = threadIdx.x;
     const int lane = tid & (WAVE - 1);
     const int wave = uniform(tid >> 6);
@@ -1807,7 +1869,8 @@ __global__ __launch_bounds__(EW * WAVE) void sfm_sym_epilogue_kernel(const TickA
         const float4 bt = a.tile_box[t];
         const float vt = a.tile_vmax[t];
         uint16_t* own = s_own[wave];
-        uint16_t* kept = s_kept[wave];
+        uint32_t* kept = s_kept[wave];
+        const bool pooled = sa.idx != nullptr;
         int n_alive = 0;
         for (int s0 = 0; s0 < sa.n_strips; s0 += WAVE) {
             const int s = s0 + lane;
@@ -1826,6 +1889,7 @@ __global__ __launch_bounds__(EW * WAVE) void sfm_sym_epilogue_kernel(const TickA
             float tv[4];
             int uu[4];
             bool ok[4];
+            uint32_t qv[4] = {0u, 0u, 0u, 0u}, sd[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int e = min(k + j, n_units - 1);
@@ -1835,13 +1899,18 @@ __global__ __launch_bounds__(EW * WAVE) void sfm_sym_epilogue_kernel(const TickA
                 uu[j] = ok[j] ? u : t;
                 tb[j] = a.tile_box[uu[j]];
                 tv[j] = a.tile_vmax[uu[j]];
+                // (the row's index is fetched WITH the box, for every candidate -- a lookup after the test would be one more dependent
+                //  round trip in a kernel that is a chain of them; a candidate that fails the test has a stale entry, never used)
+                if (pooled) qv[j] = sa.idx[pool_slot(sa, t, uu[j], sd[j])];
             }
             int n_kept = 0;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const bool keep = ok[j] && !tiles_negligible(bt, vt, tb[j], tv[j], a.ped.lam, a.cut_scale, a.cut_pad);
+                bool keep = ok[j] && !tiles_negligible(bt, vt, tb[j], tv[j], a.ped.lam, a.cut_scale, a.cut_pad);
+                uint32_t where = (uint32_t)uu[j];
+                if (keep && pooled) { where = 2u * qv[j] + sd[j]; keep = qv[j] != 0xffffffffu; }   // (spilled pairs are in the overflow sums)
                 const unsigned long long m = __ballot(keep);
-                if (keep) kept[n_kept + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)uu[j];
+                if (keep) kept[n_kept + __popcll(m & ((1ull << lane) - 1ull))] = where;
                 n_kept += __popcll(m);
             }
             for (int r = 0; r < n_kept; r += EPI_INFLIGHT) {
@@ -1849,8 +1918,9 @@ __global__ __launch_bounds__(EW * WAVE) void sfm_sym_epilogue_kernel(const TickA
                 float vz[EPI_INFLIGHT];
 #pragma unroll
                 for (int q = 0; q < EPI_INFLIGHT; ++q) {
-                    v[q] = (r + q < n_kept) ? col[(size_t)kept[r + q] * sa.stride] : make_float2(0.f, 0.f);
-                    vz[q] = (Z3 && r + q < n_kept) ? colz[(size_t)kept[r + q] * sa.stride] : 0.f;
+                    const size_t at = r + q < n_kept ? (pooled ? (size_t)kept[r + q] * WAVE + lane : (size_t)kept[r + q] * sa.stride) : 0;
+                    v[q] = (r + q < n_kept) ? (pooled ? sa.slab[at] : col[at]) : make_float2(0.f, 0.f);
+                    vz[q] = (Z3 && r + q < n_kept) ? (pooled ? sa.slabz[at] : colz[at]) : 0.f;
                 }
 #pragma unroll
                 for (int q = 0; q < EPI_INFLIGHT; q += 4) {
@@ -1867,12 +1937,14 @@ __global__ __launch_bounds__(EW * WAVE) void sfm_sym_epilogue_kernel(const TickA
         const float2* col = sa.slab + i;
         const float4 bt = a.tile_box[t];
         const float vt = a.tile_vmax[t];
-        uint16_t* kept = s_kept[wave];
+        uint32_t* kept = s_kept[wave];
+        const bool pooled = sa.idx != nullptr;
         for (int base = wave; base < sa.n_t; base += 4 * EW * WAVE) {
             float4 tb[4];
             float tv[4];
             int uu[4];
             bool ok[4];
+            uint32_t qv[4] = {0u, 0u, 0u, 0u}, sd[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int u = base + j * EW * WAVE + EW * lane;
@@ -1880,13 +1952,16 @@ __global__ __launch_bounds__(EW * WAVE) void sfm_sym_epilogue_kernel(const TickA
                 uu[j] = ok[j] ? u : t;
                 tb[j] = a.tile_box[uu[j]];
                 tv[j] = a.tile_vmax[uu[j]];
+                if (pooled) qv[j] = sa.idx[pool_slot(sa, t, uu[j], sd[j])];
             }
             int n_kept = 0;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const bool keep = ok[j] && !tiles_negligible(bt, vt, tb[j], tv[j], a.ped.lam, a.cut_scale, a.cut_pad);
+                bool keep = ok[j] && !tiles_negligible(bt, vt, tb[j], tv[j], a.ped.lam, a.cut_scale, a.cut_pad);
+                uint32_t where = (uint32_t)uu[j];
+                if (keep && pooled) { where = 2u * qv[j] + sd[j]; keep = qv[j] != 0xffffffffu; }   // (spilled pairs are in the overflow sums)
                 const unsigned long long m = __ballot(keep);
-                if (keep) kept[n_kept + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)uu[j];
+                if (keep) kept[n_kept + __popcll(m & ((1ull << lane) - 1ull))] = where;
                 n_kept += __popcll(m);
             }
             for (int r = 0; r < n_kept; r += EPI_INFLIGHT) {
@@ -1894,8 +1969,9 @@ __global__ __launch_bounds__(EW * WAVE) void sfm_sym_epilogue_kernel(const TickA
                 float vz[EPI_INFLIGHT];
 #pragma unroll
                 for (int q = 0; q < EPI_INFLIGHT; ++q) {
-                    v[q] = (r + q < n_kept) ? col[(size_t)kept[r + q] * sa.stride] : make_float2(0.f, 0.f);
-                    vz[q] = (Z3 && r + q < n_kept) ? colz[(size_t)kept[r + q] * sa.stride] : 0.f;
+                    const size_t at = r + q < n_kept ? (pooled ? (size_t)kept[r + q] * WAVE + lane : (size_t)kept[r + q] * sa.stride) : 0;
+                    v[q] = (r + q < n_kept) ? (pooled ? sa.slab[at] : col[at]) : make_float2(0.f, 0.f);
+                    vz[q] = (Z3 && r + q < n_kept) ? (pooled ? sa.slabz[at] : colz[at]) : 0.f;
                 }
 #pragma unroll
                 for (int q = 0; q < EPI_INFLIGHT; q += 4) {
@@ -1926,8 +2002,17 @@ __global__ __launch_bounds__(EW * WAVE) void sfm_sym_epilogue_kernel(const TickA
     if (Z3) s_sumz[Z3 ? wave : 0][lane] = accz;
     // A coincident pair leaves a NaN (moussaid_planar) in the sums of both pedestrians: any non-finite partial sum sends the
     // whole tile through the exact body below.
+    // (list mode with the row pool: pairs beyond its capacity left their sums in ovf[] -- 2^-36 fixed point, this tick's serial in
+    //  ovf_tick -- and a non-finite one a count in the fourth plane; wave 0 takes them in and clears them for the next tick)
+    const bool spilled = sa.idx != nullptr && a.en_ped && sa.spill->tick == sa.tick_serial;
+    long long ov[4] = {0, 0, 0, 0};
+    if (spilled && wave == 0 && i < a.N_pad) {
+        long long* ovf = sa.spill->ovf;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { ov[k] = ovf[(size_t)k * a.N_pad + i]; ovf[(size_t)k * a.N_pad + i] = 0; }
+    }
     {
-        const bool bad = !(fabsf(acc.x) < __builtin_inff()) || !(fabsf(acc.y) < __builtin_inff()) || (Z3 && !(fabsf(accz) < __builtin_inff()));
+        const bool bad = !(fabsf(acc.x) < __builtin_inff()) || !(fabsf(acc.y) < __builtin_inff()) || (Z3 && !(fabsf(accz) < __builtin_inff())) || ov[3] != 0;
         if (lane == 0) s_bad[wave] = 0;
         if (bad) s_bad[wave] = 1;                                  // same wave, LDS operations in order
     }
@@ -1977,12 +2062,14 @@ __global__ __launch_bounds__(EW * WAVE) void sfm_sym_epilogue_kernel(const TickA
     float2 g = s_sum[0][lane];
 #pragma unroll
     for (int w = 1; w < EW; ++w) { const float2 b = s_sum[w][lane]; g.x += b.x; g.y += b.y; }
+    if (spilled) { g.x = (float)((double)g.x + (double)ov[0] * 0x1p-36); g.y = (float)((double)g.y + (double)ov[1] * 0x1p-36); }
     if (exact) g = s_exact[lane];
     float gz = 0.f;
     if (Z3) {
         gz = s_sumz[0][lane];
 #pragma unroll
         for (int w = 1; w < (Z3 ? EW : 1); ++w) gz += s_sumz[w][lane];
+        if (spilled) gz = (float)((double)gz + (double)ov[2] * 0x1p-36);
         if (exact) gz = s_exactz[lane];
     }
     const float fpx = a.en_ped ? a.ped.negA * g.x : 0.f, fpy = a.en_ped ? a.ped.negA * g.y : 0.f;
@@ -2662,7 +2749,7 @@ hipError_t launch_sym_list(const TickArgs& a, const SymArgs& sa, hipStream_t st,
     else
         hipLaunchKernelGGL(sfm_pair_list_kernel, dim3((sa.t_hi - sa.t_lo + 255) / 256, whole ? sa.n_t / 2 + 1 : sa.n_t), dim3(256), 0, st,
                            a.tile_box, a.tile_vmax, sa.n_t, sa.t_lo, sa.t_hi, a.ped.lam, a.cut_scale, a.cut_pad,
-                           const_cast<uint32_t*>(sa.work), const_cast<int*>(sa.work_count), partners);
+                           const_cast<uint32_t*>(sa.work), const_cast<int*>(sa.work_count), partners, sa.idx, sa.row_base, sa.cap_pairs);
     return hipGetLastError();
 }
 

@@ -11,6 +11,7 @@ the CPU ``gloo`` tests drive the same partition / collective logic with a host e
 from __future__ import annotations
 
 import os
+import time
 
 import numpy as np
 
@@ -215,8 +216,16 @@ class ShardedStepper:
     boundaries move so that every rank carries the same pair work (``balanced_bounds``; the measure is the engine's
     ``work()``, all-gathered, so every rank computes the same new boundaries)."""
 
-    def __init__(self, engine, scenario, rank=0, world=1, group=None, redraw=True, resort_every=None, balance=True, layout=None):
+    def __init__(self, engine, scenario, rank=0, world=1, group=None, redraw=True, resort_every=None, balance=True, layout=None,
+                 split="auto"):
         self.engine, self.rank, self.world, self.group, self.redraw = engine, rank, world, group, redraw
+        # The split tick (engine.begin beside the exchange, engine.end after it) hides the all-gather behind the own-own pair work at
+        # the price of three more launches per tick (~15-20 us on one replayed rank of c5, tools/shard_rank_time.py); whether that
+        # pays depends on what the collective costs on the node at hand.  "auto": the first ticks alternate between the two forms in
+        # blocks of three, timed with a device synchronisation, and after eight samples of each the faster one (max over ranks of the
+        # medians, so that every rank decides alike) is kept.  Both forms compute the same bits.
+        self.split_mode = split if (world > 1 and hasattr(engine, "begin")) else False
+        self._split_samples = {True: [], False: []}
         # rank blocks instead of slabs: every rank's rows are the pedestrians of one rectangle of a gx x gy grid over the map
         self.layout = block_layout(world, layout) if (world > 1 and hasattr(engine, "set_partition")) else None
         if self.layout:
@@ -340,13 +349,22 @@ class ShardedStepper:
         if self.world == 1 and not driver_resorts:
             self.engine.run(ticks, redraw=self.redraw)      # no exchange needed: launch back to back
         else:
-            split = self.world > 1 and hasattr(self.engine, "begin")
             pending = None
             for _ in range(ticks):
                 if driver_resorts and self.since_resort >= self.resort_every:
                     self._gather_finish(pending)
                     pending = None
                     self._repack()
+                probing = self.split_mode == "auto"
+                if probing:                                  # blocks of three ticks of either form, each tick timed on its own
+                    k = len(self._split_samples[True]) + len(self._split_samples[False])
+                    split = (k // 3) % 2 == 0
+                    self._gather_finish(pending)
+                    pending = None
+                    self.engine.synchronize()
+                    t0 = time.perf_counter()
+                else:
+                    split = bool(self.split_mode)
                 if split:
                     self.engine.begin(redraw=self.redraw)
                     self._gather_finish(pending)
@@ -355,9 +373,28 @@ class ShardedStepper:
                     self._gather_finish(pending)
                     self.engine.run(1, redraw=self.redraw)
                 pending = self._gather_start(self.engine.packed()) if self.world > 1 else None
+                if probing:
+                    self._gather_finish(pending)             # a probed tick pays for its own exchange
+                    pending = None
+                    self.engine.synchronize()
+                    self._split_samples[split].append(time.perf_counter() - t0)
+                    self._decide_split()
                 self.since_resort += 1
             self._gather_finish(pending)
         self.ticks_done += ticks
+
+    def _decide_split(self):
+        a, b = self._split_samples[True], self._split_samples[False]
+        if len(a) < 8 or len(b) < 8:
+            return
+        import torch
+        import torch.distributed as dist
+        dev = self.engine.packed()[0][0].device
+        t = torch.tensor([float(np.median(a[2:])), float(np.median(b[2:]))], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        split_s, plain_s = (float(v) for v in t.cpu().tolist())
+        self.split_mode = split_s < plain_s
+        self.split_probe = {"split_tick_us": split_s * 1e6, "plain_tick_us": plain_s * 1e6, "chosen": "split" if self.split_mode else "plain"}
 
     def local_rows(self):
         return self.lo, self.hi

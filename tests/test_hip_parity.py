@@ -1288,3 +1288,95 @@ def test_profiling_the_dominant_kernel_leaves_the_state_alone(z_spread):
             eng.close()
     for a, b in zip(out["profiled"], out["plain"]):
         assert np.array_equal(a, b, equal_nan=True)
+
+
+@pytest.mark.parametrize("n,z_spread,shard", [(9000, 0.0, False), (9000, 1.5, False), (12000, 0.0, True)])
+def test_row_pool_spills_into_exact_overflow_sums(n, z_spread, shard, monkeypatch):
+    """Round 4: under the tile-pair list the partial forces live in a pool of row pairs (O(kept tile pairs)) instead of the dense slab
+    (O(N^2 / 64): 8.6 GB at N = 262 144; forces.py:112-117's row sum).  A tile pair beyond the pool's capacity adds its sums to
+    per-pedestrian overflow accumulators in 2^-36 fixed point (integer atomics: order-independent, so still deterministic).  With the
+    pool squeezed to 3 row pairs per tile most pairs spill: v' must still agree with the oracle to 1e-5, with the unsqueezed run to
+    rounding, and two squeezed runs bit for bit -- planar, 3-D, with two coincident pedestrians in a spilled pair (its NaN sum sends
+    the tile through the exact body) and on a shard's split tick (two lists, two halves of the pool)."""
+    monkeypatch.setenv("SFM_POOL", "1")                          # (by default the dense slab serves crowds this small: it fits in 1 GiB)
+    sc = scenarios.make_scenario(n, 9100 + n, z_spread=z_spread)
+    sc.loc[n // 3] = sc.loc[n // 3 + 1000]                       # a coincident pair (different velocities) in different tiles
+    cfg = default_sfm_config(("acceleration_force", "pedestrian_force"))
+    prm = O.OracleParams.from_config(cfg)
+    out = {}
+    for tag, per in (("squeezed", "3"), ("again", "3"), ("roomy", None)):
+        if per is None:
+            monkeypatch.delenv("SFM_POOL_PER_TILE", raising=False)
+        else:
+            monkeypatch.setenv("SFM_POOL_PER_TILE", per)
+        eng = SfmEngine(cfg, 0.05)
+        try:
+            eng.upload_state(sc.loc, sc.vel, sc.waypoint, sc.target_speed, sc.radius, None)
+            if shard:
+                lo, hi = 4096, 8192
+                eng.set_shard(lo, hi)
+                for _ in range(3):
+                    eng.tick_begin(); eng.tick_end()                 # (the other rows stay put: only this rank's rows are compared)
+            else:
+                lo, hi = 0, n
+                eng.run(3)
+            assert "sym" in eng.kernel_variant(), eng.kernel_variant()
+            items, terms = eng.pair_work()
+            out[tag] = (eng.state(), items)
+        finally:
+            eng.close()
+    (loc_a, vel_a, _), items = out["squeezed"]
+    for x, y in zip(out["squeezed"][0], out["again"][0]):
+        assert np.array_equal(x, y, equal_nan=True)                   # deterministic although the spilled sums are atomics
+    own_tiles = (hi - lo + 63) // 64
+    assert items > 3 * own_tiles * 4, (items, own_tiles)              # most kept tile pairs were beyond the squeezed pool
+    loc_r, vel_r, _ = out["roomy"][0]
+    rows = ~np.isnan(vel_a[:, 0])
+    dev = np.abs(vel_a[rows] - vel_r[rows]).max()
+    print(f"\nrow pool squeezed vs roomy, N={n}: {items} tile-pair items on {own_tiles} own tiles, max |dv| {dev:.3g}")
+    assert dev < 2e-5
+    # one more tick from the roomy run's state against the oracle, squeezed
+    monkeypatch.setenv("SFM_POOL_PER_TILE", "3")
+    eng = SfmEngine(cfg, 0.05)
+    try:
+        eng.upload_state(sc.loc, sc.vel, sc.waypoint, sc.target_speed, sc.radius, None)
+        eng.tick()
+        v = eng.velocities()
+        for r in ((0, 128), (n // 3 - 64, n // 3 + 64), (n - 128, n)):
+            with np.errstate(all="ignore"):
+                _, _, v_new, expo, _ = c_oracle.tick(sc.loc, sc.vel, sc.waypoint, sc.target_speed, sc.radius, np.zeros(n, bool), O.Geometry(), prm, 0.05,
+                                                     rows=r, theta_tol=P.THETA_TOL)
+            P.check_velocity(v[r[0]:r[1]], v_new, expo, 0.05)
+    finally:
+        eng.close()
+
+
+def test_half_a_million_pedestrians_on_one_gpu():
+    """N = 524 288 (twice BASELINE's largest crowd) on ONE GPU: with the dense slab the symmetric path stopped at ~350 000 pedestrians
+    (n_t x N x 8 B = 34 GB here, over its 16 GiB allowance); the row pool needs 0.7 GB.  One tick with the pedestrian and acceleration
+    forces: the symmetric path ran, sum of the pedestrian forces ~ 0 (every evaluated pair contributes +f and -f: forces.py:112-117 is
+    antisymmetric), and three row blocks agree with the C oracle like the BASELINE configs do."""
+    n = 524288
+    sc = scenarios.make_scenario(n, 5242)
+    cfg = default_sfm_config(("acceleration_force", "pedestrian_force"))
+    prm = O.OracleParams.from_config(cfg)
+    eng = SfmEngine(cfg, 0.05)
+    try:
+        eng.upload_state(sc.loc, sc.vel, sc.waypoint, sc.target_speed, sc.radius, None)
+        eng.tick(integrate=True, record=True)
+        assert "sym" in eng.kernel_variant(), eng.kernel_variant()
+        items, terms = eng.pair_work()
+        F, Fp, v = eng.forces("total"), eng.forces("pedestrian_force"), eng.velocities()
+        assert np.isfinite(F).all() and np.isfinite(v).all()
+        net = np.abs(Fp.sum(axis=0)).max() / np.abs(Fp).sum()
+        print(f"\nN={n}: {items} tile-pair items ({items / (n // 64):.1f} per tile), {terms / 1e9:.2f} G terms; |sum F_ped| / sum |F_ped| = {net:.2e}")
+        assert net < 1e-6
+        for r in ((0, 128), (n // 2 - 64, n // 2 + 64), (n - 128, n)):
+            plain = np.zeros(r[1] - r[0])
+            with np.errstate(all="ignore"):
+                _, total, v_new, expo, absum = c_oracle.tick(sc.loc, sc.vel, sc.waypoint, sc.target_speed, sc.radius, np.zeros(n, bool), O.Geometry(), prm,
+                                                             0.05, rows=r, theta_tol=P.THETA_TOL, plain=plain)
+            P.check_force("total", F[r[0]:r[1]], total, absum, expo)
+            P.check_velocity(v[r[0]:r[1]], v_new, expo, 0.05)
+    finally:
+        eng.close()
