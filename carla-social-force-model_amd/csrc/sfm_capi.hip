@@ -1299,6 +1299,287 @@ static int merged_geo_slices(int tiles, int slices) {
     return tiles >= 1024 ? 1 : tiles >= 512 ? 2 : tiles >= 64 ? 4 : tiles > 32 ? 8 : 16;
 }
 
+// ---- one call of sfm_tick / sfm_run / sfm_tick_begin / sfm_tick_end -------------------------------------------------------------
+// run_ticks decides ONCE what kind of ticks the call runs (TickPlan) and hands over to the arrangement that ships for it:
+//   run_fused            a device-resident run of a whole crowd below the list cutoff: one launch per tick (above)
+//   shard_begin          first half of a shard's split tick: own tile boxes, own-own list, own-own pairs (+ geometry workgroups)
+//   tick_loop            everything else, tick by tick:  tick_boxes -> tick_geometry -> tick_symmetric | tick_ordered -> tick_carry
+//                        (whole crowd under the list cutoff with carried boxes, two-launch tick below it, a shard's plain tick or the
+//                         second half of its split tick, the ordered kernel)
+struct TickPlan {
+    int n_local, ipw, team, tps, n_strips;
+    bool order_pays;      // compact tiles matter (tile cutoff or border / obstacle forces): device re-packs are worth their launches
+    bool list_cut;        // the tile-pair list is on
+    bool plain;           // no border / obstacle forces, no list, no device-side vehicles
+    bool fused_geo;       // border / obstacle forces without the list: the fused tick's geometry role can take them
+    bool whole;           // the handle owns every row
+    bool sym;             // the symmetric path runs (else the ordered kernel)
+    bool fusable;         // ... as the one-launch tick
+    bool carry;           // the call before this one was a fused run and nothing came between
+};
+
+static int plan_ticks(SfmHandle* h, uint32_t flags, int phase, bool device_run, bool carry, TickPlan& p) {
+    p.carry = carry;
+    p.n_local = h->i_end - h->i_begin;
+    p.ipw = 1; p.team = 1;
+    pick_shape(h, p.n_local, &p.ipw, &p.team);
+    h->ipw_last = p.ipw;
+    p.tps = 1; p.n_strips = 0;
+    strip_shape(h, &p.tps, &p.n_strips);
+    {
+        TickArgs probe;
+        fill_args(h, probe, flags);
+        p.order_pays = probe.geo != nullptr || probe.tile_box != nullptr;
+        p.list_cut = probe.tile_box != nullptr;
+        p.plain = probe.geo == nullptr && probe.tile_box == nullptr && probe.adv.M == 0;
+        p.fused_geo = probe.geo != nullptr && probe.tile_box == nullptr && h->fused_geo_mode != 0;     // (SFM_FUSED=0 switches both off)
+    }
+    // symmetric path: the whole crowd on this handle, or -- tile-pair list on -- a shard of whole tiles: pairs with a tile of another
+    // rank are then evaluated one-sided by both ranks
+    p.whole = h->i_begin == 0 && h->i_end == h->N;
+    const bool tile_shard = p.n_local > 0 && (h->i_begin % WAVE) == 0 && ((h->i_end % WAVE) == 0 || h->i_end == h->N) && p.list_cut &&
+                            h->n_t < 32768;
+    const bool sym_wanted = (p.whole || tile_shard) && h->dpp_dir == 1 && h->sym_mode != 0 && h->prm.enabled[SFM_FORCE_PEDESTRIAN] &&
+                            (h->sym_mode == 1 || h->N >= 256 || device_run || carry);
+    const bool sym_any_size = sym_wanted && sym_reserve(h, p.list_cut, !p.whole && h->split_mode != 0);
+    // ---- a device-resident run of a whole crowd below the list cutoff: one launch per tick (sfm_fused_tick_kernel).
+    //      Every sfm_run / sfm_run_recorded takes it, whatever its length -- what a device-resident run computes must not depend on
+    //      how the caller cuts it into calls (a lone sfm_run(1) pays a launch in front like the two-launch tick pays its epilogue) --
+    //      and a single sfm_tick when it carries on from such a run.
+    p.fusable = p.whole && (p.plain || p.fused_geo) && phase == PHASE_FULL && (device_run || carry) && h->fused_mode != 0 &&
+                (flags & SFM_TICK_INTEGRATE) && !(flags & SFM_TICK_RECORD_FORCES) && !h->fsm_on && h->debug_steps < 0 && !h->stamps &&
+                !h->geo_stamps && h->N >= 2;
+    // Auto mode keeps host-in-the-loop ticks of crowds under 256 pedestrians on the ordered kernel (one launch against the symmetric
+    // path's two); their device-resident runs are one launch per tick on the fused kernel like everybody else's (round 3: c1).
+    const bool small_run = h->sym_mode < 0 && h->N < 256 && p.fusable;
+    p.sym = sym_any_size && (h->sym_mode == 1 || (h->sym_mode < 0 && h->N >= 256) || small_run);
+    h->used_sym = p.sym;
+    if (p.sym) snprintf(h->variant, sizeof(h->variant), "sfm_pair_sym_kernel+sfm_sym_epilogue_kernel");
+    else snprintf(h->variant, sizeof(h->variant), "sfm_tick_kernel<%d,%s,%s,%d>", p.ipw, h->z3 ? "true" : "false",
+                  h->rad ? "true" : "false", p.team);
+    h->used_fused = false;
+    return SFM_OK;
+}
+
+// the geometry kernel on the side stream, joined later through ev_join
+static int fork_geometry(SfmHandle* h, const TickArgs& a) {
+    HIP_TRY(h, hipEventRecord(h->ev_fork, h->stream));
+    HIP_TRY(h, hipStreamWaitEvent(h->aux, h->ev_fork, 0));
+    HIP_TRY(h, launch_geometry(h->rad, a, h->aux));
+    HIP_TRY(h, hipEventRecord(h->ev_join, h->aux));
+    return SFM_OK;
+}
+
+// ---- split tick of a shard, first half (sfm_tick_begin): what needs only this rank's rows -- own tile boxes, the own-own list, the
+//      own-own pairs with the border / obstacle workgroups in the same launch (sfm_pair_geo_kernel; SFM_PAIR_GEO=0: the geometry kernel
+//      on the side stream).  Anything that cannot be split: nothing happens here and sfm_tick_end runs the whole tick.
+static int shard_begin(SfmHandle* h, const TickPlan& p, uint32_t flags) {
+    h->begin_done = false;
+    if (!(p.sym && !p.whole && p.list_cut && !h->fsm_on && (flags & SFM_TICK_INTEGRATE) && p.n_local > 0 && h->split_mode != 0)) return SFM_OK;
+    const size_t items = (size_t)h->n_t * (size_t)(h->n_t / 2 + 1);
+    if (items > h->work2_cap) { HIP_TRY(h, dev_realloc(h->work2, items)); h->work2_cap = items; }
+    if (h->timing_on) HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+    ++h->ticks_since_sort;
+    ++h->tick_serial;                              // (the two halves of a split tick share it: overflow sums of both lists)
+    TickArgs a;
+    fill_args(h, a, flags);
+    const int t_lo = h->i_begin / WAVE, t_hi = (h->i_end + WAVE - 1) / WAVE;
+    HIP_TRY(h, launch_tile_bounds(a.pk_cur, h->z3 ? a.zv_cur : nullptr, h->N, const_cast<float4*>(a.tile_box), const_cast<float*>(a.tile_vmax), h->stream,
+                                  t_lo, t_hi));
+    const bool ahead = h->geo_ahead && a.geo;
+    h->geo_ahead = false;
+    const bool merged = a.geo && !ahead && a.en_ped && h->pair_geo_mode != 0 && h->debug_steps < 0 && !h->geo_stamps;
+    h->begin_forked = a.geo != nullptr && !merged;
+    h->begin_geo_slices = 0;
+    if (a.geo && !ahead && !merged) { const int rc = fork_geometry(h, a); if (rc) return rc; }
+    SymArgs sa = make_sym_args(h, a, p.tps, 0, h->debug_steps, nullptr);
+    sa.work = h->work2;
+    sa.work_count = h->work_count + 1;
+    sa.row_base = h->pool_main;                       // the own-own list's row pairs sit behind the main list's
+    HIP_TRY(h, launch_sym_list(a, sa, h->stream, LIST_OWN, h->count_zeroed));
+    if (merged) {
+        a.geo_slices = merged_geo_slices(t_hi - t_lo, a.geo_slices);
+        h->begin_geo_slices = a.geo_slices;
+        HIP_TRY(h, launch_sym_pair_geo(h->rad, a, sa, h->stream));
+    } else {
+        HIP_TRY(h, launch_sym_pair(h->rad, a, sa, h->stream));
+    }
+    h->begin_done = true;
+    h->begin_flags = flags;
+    h->timed_launches = 3 + (a.geo && !ahead && !merged ? 1 : 0);
+    return SFM_OK;
+}
+
+// what one tick of tick_loop has settled about its launches
+struct TickShape {
+    bool carried;         // the previous epilogue left this tick's tile boxes (whole crowd under the list cutoff)
+    bool merged_bounds;   // tile and strip boxes came out of one launch
+    bool geo_in_pair;     // the border / obstacle workgroups ride in the pair kernel's launch (sfm_pair_geo_kernel)
+    bool fork;            // the geometry kernel runs on the side stream and is joined before the epilogue
+    bool begun_merged;    // second half of a split tick whose first half's pair launch held the geometry workgroups
+    bool list_in_geo;     // the flat tile-pair list was built by extra workgroups of the geometry launch
+    bool shard_zeroed;    // the epilogue left a shard's list counters at zero
+};
+
+// boxes / largest speeds of this tick's input state (all tiles) unless the previous epilogue carried them over; with the two-level
+// list the strips' boxes come out of the same launch
+static int tick_boxes(SfmHandle* h, const TickPlan& p, const TickArgs& a, TickShape& s, int* launches) {
+    s.carried = a.tile_box_out != nullptr && h->boxes_valid;
+    s.merged_bounds = a.tile_box && !s.carried && p.sym && p.list_cut && p.n_strips > 0 && !h->z3;
+    if (s.merged_bounds) {
+        HIP_TRY(h, launch_tile_strip_bounds(a.pk_cur, h->N, h->n_t, p.tps, p.n_strips, const_cast<float4*>(a.tile_box),
+                                            const_cast<float*>(a.tile_vmax), h->strip_box, h->strip_vmax, h->stream));
+        ++*launches;
+    } else if (a.tile_box && !s.carried) {
+        HIP_TRY(h, launch_tile_bounds(a.pk_cur, h->z3 ? a.zv_cur : nullptr, h->N, const_cast<float4*>(a.tile_box), const_cast<float*>(a.tile_vmax), h->stream));
+        ++*launches;
+    }
+    return SFM_OK;
+}
+
+// Where the border / obstacle forces of the tick run.  They only need the tick's input state.
+//  * in the pair kernel's launch (sfm_pair_geo_kernel), the default with the symmetric path: whole crowd under the list cutoff --
+//    mid-sized: four 4-wave workgroups per tile, first in the grid, c3 41.5 -> 35.1 us; two-level list: one per tile spread evenly over
+//    the grid, c5 792 us with the geometry kernel on the side stream, 778 us this way (812 us with 8 192 of them in front of the pair
+//    workgroups: they hold every slot for four rounds) -- and whole crowds below the cutoff (the pair kernel's 2-D grid): all forces at
+//    N = 512 / 2048 / 4096: 38.9 / 37.9 / 43.6 us with the geometry kernel on the side stream (round 1's default), 19.3 / 22.2 / 31.0 us
+//    with it in line on the main stream, 13.9 / 16.3 / 23.2 us in the pair kernel's launch (tools/mid_crowd_probe.py);
+//  * on the side stream, joined before the epilogue: shards without the merged launch (beside the exchange and the list) and large whole
+//    crowds whose boxes are not carried (c5 825 us in line, 799 us forked); a mid-sized whole crowd keeps it in line -- with carried
+//    boxes nothing small runs in front of the list / pair kernels any more, their resident grid takes every wave slot before the side
+//    stream's workgroups get in and the two end up back to back behind a cross-stream wait: c3 65 us forked against 45 us in line;
+//  * in line on the main stream otherwise (the ordered kernel consumes them itself); a whole crowd with a flat list, carried boxes and
+//    a zeroed counter then has the LIST built by extra workgroups of that launch (c3: 4 -> 3 launches).
+static int tick_geometry(SfmHandle* h, const TickPlan& p, TickArgs& a, bool finishing, TickShape& s, int* launches) {
+    const bool ahead = (h->geo_ahead && a.geo && p.n_local > 0 && p.sym) ||   // launched at the end of the previous tick ...
+                       (finishing && h->begin_forked);                         // ... or by sfm_tick_begin: join only
+    h->geo_ahead = false;
+    static const int fork_ov = exp_env("SFM_FORK") ? atoi(exp_env("SFM_FORK")) : -1;      // A/B only: 0 / 1 = in line / side stream with carried boxes
+    const bool fork_carried = fork_ov >= 0 ? fork_ov == 1 : h->n_t >= 1024;
+    const bool plain_grid = !a.tile_box;                           // no cutoff: the pair kernel runs its 2-D grid
+    s.geo_in_pair = !ahead && a.geo && p.n_local > 0 && p.sym && !finishing && a.en_ped && h->N > 1 && h->debug_steps < 0 &&
+                    !h->stamps && !h->geo_stamps && h->pair_geo_mode != 0 && (p.list_cut || plain_grid);
+    s.fork = !s.geo_in_pair && a.geo && p.n_local > 0 && p.sym && ((h->overlap_geo && (!p.whole || fork_carried)) || finishing);
+    s.list_in_geo = false;
+    if (s.geo_in_pair) a.geo_slices = merged_geo_slices((h->i_end + WAVE - 1) / WAVE - h->i_begin / WAVE, a.geo_slices);
+    if (finishing && h->begin_geo_slices > 0) a.geo_slices = h->begin_geo_slices;      // sfm_tick_begin's pair launch held the geometry workgroups
+    s.begun_merged = finishing && h->begin_geo_slices > 0;        // the geometry forces of this tick are already there
+    if (s.geo_in_pair || s.begun_merged || ahead) return SFM_OK;
+    if (s.fork) {
+        const int rc = fork_geometry(h, a);
+        if (rc) return rc;
+        ++*launches;
+    } else if (a.geo && p.n_local > 0) {
+        s.list_in_geo = p.sym && p.whole && s.carried && h->count_zeroed && p.list_cut && p.n_strips == 0 && !finishing && a.en_ped &&
+                        h->N > 1 && h->list_merge_mode != 0;
+        if (s.list_in_geo) { a.list_work = h->work; a.list_count = h->work_count; a.list_n_t = h->n_t; a.list_idx = h->pooled ? h->pair_idx : nullptr; a.list_cap = h->pool_main; }
+        HIP_TRY(h, launch_geometry(h->rad, a, h->stream));
+        ++*launches;
+    }
+    return SFM_OK;
+}
+
+// the symmetric path's launches of one tick: [strip boxes] -> [tile-pair list] -> pair kernel (+ geometry workgroups) -> epilogue
+static int tick_symmetric(SfmHandle* h, const TickPlan& p, const TickArgs& a, bool finishing, TickShape& s, int* launches) {
+    const SymArgs sa = make_sym_args(h, a, p.tps, p.n_strips, h->debug_steps, h->stamps);
+    h->last_list = sa.work != nullptr;
+    if (sa.work && p.n_strips > 0 && !s.merged_bounds) {
+        HIP_TRY(h, launch_strip_bounds(a.tile_box, a.tile_vmax, h->n_t, p.tps, p.n_strips, h->strip_box, h->strip_vmax, h->stream));
+        ++*launches;
+    }
+    // a shard's epilogue leaves the list counter(s) at zero as well (its boxes cannot be carried -- the other ranks' rows
+    // arrive in between -- but the memset can go)
+    const bool shard_zero = !p.whole && p.list_cut && h->carry_mode != 0;
+    if (sa.work && !s.list_in_geo) {
+        HIP_TRY(h, launch_sym_list(a, sa, h->stream, finishing ? LIST_REMOTE : LIST_ALL, (s.carried || !p.whole) && h->count_zeroed));
+        ++*launches;
+    }
+    if (s.geo_in_pair) HIP_TRY(h, launch_sym_pair_geo(h->rad, a, sa, h->stream));
+    else HIP_TRY(h, launch_sym_pair(h->rad, a, sa, h->stream));
+    if (s.fork && !s.begun_merged) HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
+    SymArgs se = sa;
+    if (shard_zero) se.zero_count = 2;
+    HIP_TRY(h, launch_sym_epilogue(h->rad, a, se, h->stream));
+    s.shard_zeroed = shard_zero;
+    *launches += 2;
+    return SFM_OK;
+}
+
+// what a tick leaves for the next one: a shard's next geometry forces started beside the exchange, carried boxes, the clock, vehicles
+static int tick_carry(SfmHandle* h, const TickPlan& p, const TickArgs& a, uint32_t flags, bool last, const TickShape& s, int* launches) {
+    // a shard's next geometry forces only need its own new rows: start them now, beside the exchange the caller issues next
+    //  (not when the geometry workgroups ride in the pair launches: then the next sfm_tick_begin / sfm_tick hosts them)
+    if (p.sym && s.fork && !s.begun_merged && !p.whole && (flags & SFM_TICK_INTEGRATE) && !h->fsm_on && h->geo_ahead_mode != 0 && last &&
+        !(flags & SFM_TICK_RECORD_FORCES)) {
+        TickArgs nx;
+        fill_args(h, nx, flags);
+        const int rc = fork_geometry(h, nx);
+        if (rc) return rc;
+        h->geo_ahead = true;
+        ++*launches;
+    }
+    // the epilogue left the next tick's boxes in the other buffer (valid only if this tick moved the crowd)
+    if (a.tile_box_out && p.sym) {
+        h->box_cur ^= 1;
+        h->boxes_valid = (flags & SFM_TICK_INTEGRATE) != 0;
+        h->count_zeroed = true;
+    } else {
+        h->boxes_valid = false;
+        h->count_zeroed = s.shard_zeroed;
+    }
+    if (h->fsm_on) h->sim_time += h->prm.step_length;
+    // CARLA-free runs: the vehicles move between ticks (run_simulation.py:77-95)
+    if (a.adv.M > 0 && p.n_local <= 0) {          // a rank without rows still has to move its copy of the vehicles
+        HIP_TRY(h, launch_dynamic_boxes(h->dynamics.ctr, h->dynamics.off, h->dyn_local, h->dyn_rot, h->dynamics.pts,
+                                        h->dynamics.K, h->prm.step_length, 1, h->stream));
+        ++*launches;
+    }
+    return SFM_OK;
+}
+
+// ---- ticks one by one: host-in-the-loop sfm_tick, sfm_run above the list cutoff, a shard's plain tick, and (finishing) the second
+//      half of its split tick -- the own-own pairs of that tick are already in the slab / pool
+static int tick_loop(SfmHandle* h, const TickPlan& p, int ticks, uint32_t flags, bool finishing) {
+    int rc;
+    if (finishing) snprintf(h->variant, sizeof(h->variant), "sfm_pair_sym_kernel(own|remote)+sfm_sym_epilogue_kernel");
+    h->begin_done = false;
+    h->last_split = finishing;
+    if (!finishing && h->timing_on) HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+    int launches = finishing ? h->timed_launches : 0;
+    for (int t = 0; t < ticks; ++t) {
+        if (h->reordered && h->resort_every > 0 && (flags & SFM_TICK_INTEGRATE) && p.whole && h->ticks_since_sort >= h->resort_every &&
+            p.order_pays) {
+            rc = resort_rows(h);
+            if (rc) return rc;
+            launches += 5;
+        }
+        if (!finishing) { ++h->ticks_since_sort; ++h->tick_serial; }
+        TickArgs a;
+        fill_args(h, a, flags);
+        if (h->fsm_on && p.n_local > 0) {           // modes first: target speeds and the border mask feed the forces
+            HIP_TRY(h, launch_modes(a, h->stream));
+            ++launches;
+        }
+        TickShape s{};
+        if ((rc = tick_boxes(h, p, a, s, &launches)) != SFM_OK) return rc;
+        if ((rc = tick_geometry(h, p, a, finishing, s, &launches)) != SFM_OK) return rc;
+        if (p.sym) {
+            if ((rc = tick_symmetric(h, p, a, finishing, s, &launches)) != SFM_OK) return rc;
+        } else if (p.n_local > 0) {
+            HIP_TRY(h, launch_tick(p.ipw, p.team, h->z3, h->rad, a, h->stream));      // the ordered kernel: the whole tick in one launch
+            ++launches;
+        }
+        h->cur ^= 1;
+        if ((rc = tick_carry(h, p, a, flags, t + 1 == ticks, s, &launches)) != SFM_OK) return rc;
+    }
+    if (h->timing_on) HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
+    h->timed_ticks = ticks;
+    h->timed_launches = launches;
+    h->timing_valid = h->timing_on;
+    h->rec_valid = (flags & SFM_TICK_RECORD_FORCES) != 0;
+    return SFM_OK;
+}
+
 static int run_ticks(SfmHandle* h, int ticks, uint32_t flags, int phase = PHASE_FULL, bool device_run = false) {
     int rc = bind(h);
     if (rc) return rc;
@@ -1309,238 +1590,12 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags, int phase = PHASE_
     if (phase != PHASE_END) h->timing_valid = false;
     if (h->N == 0 || ticks == 0) return SFM_OK;        // tick() early-out (pedestrian_simulation.py:60-61)
     if (!h->pk[0]) return fail(h, SFM_ERR_STATE, "sfm_upload_state has not been called");
-    const int n_local = h->i_end - h->i_begin;
-    int ipw = 1, team = 1;
-    pick_shape(h, n_local, &ipw, &team);
-    h->ipw_last = ipw;
-    int tps = 1, n_strips = 0;
-    strip_shape(h, &tps, &n_strips);
-    // symmetric path: planar crowd, the whole of it on this handle or a tile-aligned shard; auto mode wants >= 4 tiles
-    bool order_pays, list_cut, plain, fused_geo;    // compact tiles only matter to the tile cutoff and the geometry kernel
-    {
-        TickArgs probe;
-        fill_args(h, probe, flags);
-        order_pays = probe.geo != nullptr || probe.tile_box != nullptr;
-        list_cut = probe.tile_box != nullptr;
-        plain = probe.geo == nullptr && probe.tile_box == nullptr && probe.adv.M == 0;
-        fused_geo = probe.geo != nullptr && probe.tile_box == nullptr && h->fused_geo_mode != 0;     // (SFM_FUSED=0 switches both off)
-    }
-    // a shard can use it too when its rows are whole tiles and the tile-pair list is on: pairs with a tile of another
-    // rank are then evaluated one-sided by both ranks
-    const bool whole = h->i_begin == 0 && h->i_end == h->N;
-    const bool tile_shard = n_local > 0 && (h->i_begin % WAVE) == 0 && ((h->i_end % WAVE) == 0 || h->i_end == h->N) && list_cut &&
-                            h->n_t < 32768;
-    const bool sym_wanted = (whole || tile_shard) && h->dpp_dir == 1 && h->sym_mode != 0 && h->prm.enabled[SFM_FORCE_PEDESTRIAN] &&
-                            (h->sym_mode == 1 || h->N >= 256 || device_run || carry);
-    const bool sym_any_size = sym_wanted && sym_reserve(h, list_cut, !whole && h->split_mode != 0);
-    // ---- a device-resident run of a whole crowd below the list cutoff: one launch per tick (sfm_fused_tick_kernel).
-    //      Every sfm_run / sfm_run_recorded takes it, whatever its length -- what a device-resident run computes must not depend on
-    //      how the caller cuts it into calls (a lone sfm_run(1) pays a launch in front like the two-launch tick pays its epilogue) --
-    //      and a single sfm_tick when it carries on from such a run.
-    const bool fusable = whole && (plain || fused_geo) && phase == PHASE_FULL && (device_run || carry) && h->fused_mode != 0 &&
-                         (flags & SFM_TICK_INTEGRATE) && !(flags & SFM_TICK_RECORD_FORCES) && !h->fsm_on && h->debug_steps < 0 && !h->stamps &&
-                         !h->geo_stamps && h->N >= 2;
-    // Auto mode keeps host-in-the-loop ticks of crowds under 256 pedestrians on the ordered kernel (one launch against the symmetric
-    // path's two); their device-resident runs are one launch per tick on the fused kernel like everybody else's (round 3: c1).
-    const bool small_run = h->sym_mode < 0 && h->N < 256 && fusable;
-    const bool sym = sym_any_size && (h->sym_mode == 1 || (h->sym_mode < 0 && h->N >= 256) || small_run);
-    h->used_sym = sym;
-    if (sym) snprintf(h->variant, sizeof(h->variant), "sfm_pair_sym_kernel+sfm_sym_epilogue_kernel");
-    else snprintf(h->variant, sizeof(h->variant), "sfm_tick_kernel<%d,%s,%s,%d>", ipw, h->z3 ? "true" : "false",
-                  h->rad ? "true" : "false", team);
-    h->used_fused = false;
-    if (sym && fusable) return run_fused(h, ticks, flags, carry, fused_geo);
-    // ---- split tick of a shard: what needs only this rank's rows first (sfm_tick_begin), the rest once the exchange is in
-    //      (sfm_tick_end).  Anything else: sfm_tick_begin does nothing and sfm_tick_end runs the whole tick.
-    if (phase == PHASE_BEGIN) {
-        h->begin_done = false;
-        if (!(sym && !whole && list_cut && !h->fsm_on && (flags & SFM_TICK_INTEGRATE) && n_local > 0 && h->split_mode != 0)) return SFM_OK;
-        const size_t items = (size_t)h->n_t * (size_t)(h->n_t / 2 + 1);
-        if (items > h->work2_cap) { HIP_TRY(h, dev_realloc(h->work2, items)); h->work2_cap = items; }
-        if (h->timing_on) HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
-        ++h->ticks_since_sort;
-        ++h->tick_serial;                              // (the two halves of a split tick share it: overflow sums of both lists)
-        TickArgs a;
-        fill_args(h, a, flags);
-        const int t_lo = h->i_begin / WAVE, t_hi = (h->i_end + WAVE - 1) / WAVE;
-        HIP_TRY(h, launch_tile_bounds(a.pk_cur, h->z3 ? a.zv_cur : nullptr, h->N, const_cast<float4*>(a.tile_box), const_cast<float*>(a.tile_vmax), h->stream,
-                                      t_lo, t_hi));
-        const bool ahead = h->geo_ahead && a.geo;
-        h->geo_ahead = false;
-        // the border / obstacle forces only need the own rows: their workgroups go into the launch of the own-own pairs
-        // (sfm_pair_geo_kernel), or -- SFM_PAIR_GEO=0 -- the geometry kernel runs on the side stream
-        const bool merged = a.geo && !ahead && a.en_ped && h->pair_geo_mode != 0 && h->debug_steps < 0 && !h->geo_stamps;
-        h->begin_forked = a.geo != nullptr && !merged;
-        h->begin_geo_slices = 0;
-        if (a.geo && !ahead && !merged) {
-            HIP_TRY(h, hipEventRecord(h->ev_fork, h->stream));
-            HIP_TRY(h, hipStreamWaitEvent(h->aux, h->ev_fork, 0));
-            HIP_TRY(h, launch_geometry(h->rad, a, h->aux));
-            HIP_TRY(h, hipEventRecord(h->ev_join, h->aux));
-        }
-        SymArgs sa = make_sym_args(h, a, tps, 0, h->debug_steps, nullptr);
-        sa.work = h->work2;
-        sa.work_count = h->work_count + 1;
-        sa.row_base = h->pool_main;                       // the own-own list's row pairs sit behind the main list's
-        HIP_TRY(h, launch_sym_list(a, sa, h->stream, LIST_OWN, h->count_zeroed));
-        if (merged) {
-            a.geo_slices = merged_geo_slices(t_hi - t_lo, a.geo_slices);
-            h->begin_geo_slices = a.geo_slices;
-            HIP_TRY(h, launch_sym_pair_geo(h->rad, a, sa, h->stream));
-        } else {
-            HIP_TRY(h, launch_sym_pair(h->rad, a, sa, h->stream));
-        }
-        h->begin_done = true;
-        h->begin_flags = flags;
-        h->timed_launches = 3 + (a.geo && !ahead && !merged ? 1 : 0);
-        return SFM_OK;
-    }
-    const bool finishing = phase == PHASE_END && h->begin_done;   // the own-own pairs of this tick are already in the slab
-    if (finishing) snprintf(h->variant, sizeof(h->variant), "sfm_pair_sym_kernel(own|remote)+sfm_sym_epilogue_kernel");
-    h->begin_done = false;
-    h->last_split = finishing;
-    if (!finishing && h->timing_on) HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
-    int launches = finishing ? h->timed_launches : 0;
-    for (int t = 0; t < ticks; ++t) {
-        if (h->reordered && h->resort_every > 0 && (flags & SFM_TICK_INTEGRATE) && h->i_begin == 0 && h->i_end == h->N &&
-            h->ticks_since_sort >= h->resort_every && order_pays) {
-            rc = resort_rows(h);
-            if (rc) return rc;
-            launches += 5;
-        }
-        if (!finishing) { ++h->ticks_since_sort; ++h->tick_serial; }
-        bool shard_zeroed = false;
-        TickArgs a;
-        fill_args(h, a, flags);
-        // border / obstacle forces only need the tick's input state.  With the symmetric path they run on the side
-        // stream beside the list / pair kernels and join before the epilogue (both are VALU-bound, so this buys a head
-        // start rather than an overlap: DESIGN.md 3.4); the ordered kernel consumes them itself, so there they run first.
-        if (h->fsm_on && n_local > 0) {           // modes first: target speeds and the border mask feed the forces
-            HIP_TRY(h, launch_modes(a, h->stream));
-            ++launches;
-        }
-        const bool carried = a.tile_box_out != nullptr && h->boxes_valid;   // the previous epilogue left this tick's boxes
-        // boxes / speeds of this tick's input state (all tiles); with the two-level list the strips' boxes come out of the same launch
-        const bool merged_bounds = a.tile_box && !carried && sym && list_cut && n_strips > 0 && !h->z3;
-        if (merged_bounds) {
-            HIP_TRY(h, launch_tile_strip_bounds(a.pk_cur, h->N, h->n_t, tps, n_strips, const_cast<float4*>(a.tile_box),
-                                                const_cast<float*>(a.tile_vmax), h->strip_box, h->strip_vmax, h->stream));
-            ++launches;
-        } else if (a.tile_box && !carried) {
-            HIP_TRY(h, launch_tile_bounds(a.pk_cur, h->z3 ? a.zv_cur : nullptr, h->N, const_cast<float4*>(a.tile_box), const_cast<float*>(a.tile_vmax), h->stream));
-            ++launches;
-        }
-        const bool ahead = (h->geo_ahead && a.geo && n_local > 0 && sym) ||   // launched at the end of the previous tick ...
-                           (finishing && h->begin_forked);                     // ... or by sfm_tick_begin: join only
-        h->geo_ahead = false;
-        // (whole crowd with carried boxes: nothing small runs in front of the list / pair kernels any more, their resident grid
-        //  takes every wave slot before the side stream's workgroups get in and the two end up back to back behind a cross-stream
-        //  wait -- c3 65 us forked against 45 us in line; so up to mid-sized crowds the geometry kernel goes first, on the main
-        //  stream (the mirror image -- geometry first on the main stream, list + pair kernel on the side stream -- 53 us).  From
-        //  ~1000 tiles on the pair kernel runs for hundreds of microseconds in many rounds of workgroups and the
-        //  geometry workgroups do get in between them: c5 825 us in line, 799 us forked.)
-        static const int fork_ov = exp_env("SFM_FORK") ? atoi(exp_env("SFM_FORK")) : -1;      // A/B only: 0 / 1 = in line / side stream with carried boxes
-        const bool fork_carried = fork_ov >= 0 ? fork_ov == 1 : h->n_t >= 1024;
-        // Whole crowd under the list cutoff, boxes and a zeroed list counter carried over: the geometry workgroups go into the pair
-        // kernel's launch (sfm_pair_geo_kernel) behind the launch(es) of the list, and overlap with the pair workgroups on the CUs.
-        // Mid-sized crowd: four 4-wave workgroups per tile, first in the grid -- c3 41.5 -> 35.1 us.  Large crowd (two-level list):
-        // one 4-wave workgroup per tile, spread evenly over the grid -- c5 792 us with the geometry kernel on the side stream,
-        // 778 us this way (812 us with 8 192 of them in front of the pair workgroups: they hold every slot for four rounds).
-        // A whole crowd below the list cutoff (no list, the pair kernel's 2-D grid) gets the same arrangement on every tick, the
-        // geometry workgroups first in the grid with as many waves per tile as the geometry kernel would use: all forces at
-        // N = 512 / 2048 / 4096: 38.9 / 37.9 / 43.6 us with the geometry kernel on the side stream (round 1's default), 19.3 / 22.2 /
-        // 31.0 us with it in line on the main stream, 13.9 / 16.3 / 23.2 us in the pair kernel's launch (tools/mid_crowd_probe.py).
-        const bool plain_grid = !a.tile_box;                           // no cutoff: the pair kernel runs its 2-D grid
-        const bool geo_in_pair = !ahead && a.geo && n_local > 0 && sym && !finishing && a.en_ped && h->N > 1 && h->debug_steps < 0 &&
-                                 !h->stamps && !h->geo_stamps && h->pair_geo_mode != 0 && (list_cut || plain_grid);
-        // the geometry kernel on the side stream: shards (beside the exchange and the list), and large whole crowds whose boxes are
-        // not carried; a mid-sized whole crowd keeps it in line -- two streams cost it a factor of two (numbers above)
-        const bool fork = !geo_in_pair && a.geo && n_local > 0 && sym &&
-                          ((h->overlap_geo && (!whole || fork_carried)) || finishing);
-        bool list_in_geo = false;
-        if (geo_in_pair) a.geo_slices = merged_geo_slices((h->i_end + WAVE - 1) / WAVE - h->i_begin / WAVE, a.geo_slices);
-        if (finishing && h->begin_geo_slices > 0) a.geo_slices = h->begin_geo_slices;      // sfm_tick_begin's pair launch held the geometry workgroups
-        const bool begun_merged = finishing && h->begin_geo_slices > 0;       // the geometry forces of this tick are already there
-        if (geo_in_pair || begun_merged) {
-        } else if (ahead) {
-        } else if (fork) {
-            HIP_TRY(h, hipEventRecord(h->ev_fork, h->stream));
-            HIP_TRY(h, hipStreamWaitEvent(h->aux, h->ev_fork, 0));
-            HIP_TRY(h, launch_geometry(h->rad, a, h->aux));
-            HIP_TRY(h, hipEventRecord(h->ev_join, h->aux));
-            ++launches;
-        } else if (a.geo && n_local > 0) {
-            // whole crowd, flat list, boxes and a zeroed counter carried over from the previous epilogue: the list is built by extra
-            // workgroups of this launch instead of a launch of its own between the geometry and the pair kernel (c3: 4 -> 3 launches)
-            list_in_geo = sym && whole && carried && h->count_zeroed && list_cut && n_strips == 0 && !finishing && a.en_ped &&
-                          h->N > 1 && h->list_merge_mode != 0;
-            if (list_in_geo) { a.list_work = h->work; a.list_count = h->work_count; a.list_n_t = h->n_t; a.list_idx = h->pooled ? h->pair_idx : nullptr; a.list_cap = h->pool_main; }
-            HIP_TRY(h, launch_geometry(h->rad, a, h->stream));
-            ++launches;
-        }
-        if (sym) {
-            const SymArgs sa = make_sym_args(h, a, tps, n_strips, h->debug_steps, h->stamps);
-            h->last_list = sa.work != nullptr;
-            if (sa.work && n_strips > 0 && !merged_bounds) {
-                HIP_TRY(h, launch_strip_bounds(a.tile_box, a.tile_vmax, h->n_t, tps, n_strips, h->strip_box, h->strip_vmax, h->stream));
-                ++launches;
-            }
-            // a shard's epilogue leaves the list counter(s) at zero as well (its boxes cannot be carried -- the other ranks' rows
-            // arrive in between -- but the memset can go)
-            const bool shard_zero = !whole && list_cut && h->carry_mode != 0;
-            if (sa.work && !list_in_geo) {
-                HIP_TRY(h, launch_sym_list(a, sa, h->stream, finishing ? LIST_REMOTE : LIST_ALL, (carried || !whole) && h->count_zeroed));
-                ++launches;
-            }
-            if (geo_in_pair) HIP_TRY(h, launch_sym_pair_geo(h->rad, a, sa, h->stream));
-            else HIP_TRY(h, launch_sym_pair(h->rad, a, sa, h->stream));
-            if (fork && !begun_merged) HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
-            SymArgs se = sa;
-            if (shard_zero) se.zero_count = 2;
-            HIP_TRY(h, launch_sym_epilogue(h->rad, a, se, h->stream));
-            shard_zeroed = shard_zero;
-            launches += 2;
-        } else if (n_local > 0) {
-            HIP_TRY(h, launch_tick(ipw, team, h->z3, h->rad, a, h->stream));
-            ++launches;
-        }
-        h->cur ^= 1;
-        // a shard's next geometry forces only need its own new rows: start them now, beside the exchange the caller issues next
-        //  (not when the geometry workgroups ride in the pair launches: then the next sfm_tick_begin / sfm_tick hosts them)
-        if (sym && fork && !begun_merged && !whole && (flags & SFM_TICK_INTEGRATE) && !h->fsm_on && h->geo_ahead_mode != 0 && t + 1 == ticks &&
-            !(flags & SFM_TICK_RECORD_FORCES)) {
-            TickArgs nx;
-            fill_args(h, nx, flags);
-            HIP_TRY(h, hipEventRecord(h->ev_fork, h->stream));
-            HIP_TRY(h, hipStreamWaitEvent(h->aux, h->ev_fork, 0));
-            HIP_TRY(h, launch_geometry(h->rad, nx, h->aux));
-            HIP_TRY(h, hipEventRecord(h->ev_join, h->aux));
-            h->geo_ahead = true;
-            ++launches;
-        }
-        // the epilogue left the next tick's boxes in the other buffer (valid only if this tick moved the crowd)
-        if (a.tile_box_out && sym) {
-            h->box_cur ^= 1;
-            h->boxes_valid = (flags & SFM_TICK_INTEGRATE) != 0;
-            h->count_zeroed = true;
-        } else {
-            h->boxes_valid = false;
-            h->count_zeroed = shard_zeroed;
-        }
-        if (h->fsm_on) h->sim_time += h->prm.step_length;
-        // CARLA-free runs: the vehicles move between ticks (run_simulation.py:77-95)
-        if (a.adv.M > 0 && n_local <= 0) {          // a rank without rows still has to move its copy of the vehicles
-            HIP_TRY(h, launch_dynamic_boxes(h->dynamics.ctr, h->dynamics.off, h->dyn_local, h->dyn_rot, h->dynamics.pts,
-                                            h->dynamics.K, h->prm.step_length, 1, h->stream));
-            ++launches;
-        }
-    }
-    if (h->timing_on) HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
-    h->timed_ticks = ticks;
-    h->timed_launches = launches;
-    h->timing_valid = h->timing_on;
-    h->rec_valid = (flags & SFM_TICK_RECORD_FORCES) != 0;
-    return SFM_OK;
+    TickPlan p;
+    rc = plan_ticks(h, flags, phase, device_run, carry, p);
+    if (rc) return rc;
+    if (p.sym && p.fusable) return run_fused(h, ticks, flags, carry, p.fused_geo);
+    if (phase == PHASE_BEGIN) return shard_begin(h, p, flags);
+    return tick_loop(h, p, ticks, flags, phase == PHASE_END && h->begin_done);
 }
 
 int sfm_profile_dominant_kernel(SfmHandle* h, int reps, float* avg_us) {
