@@ -19,11 +19,15 @@
 // summation orders: every result is deterministic run to run.
 #include "sfm_device.h"
 
+#ifndef SFM_X2
+#define SFM_X2 1                       // 1: the fused tick's planar step (no use_ped_radius) evaluates TWO pairs per lane on packed fp32 (A/B, round 4)
+#endif
 #ifndef SFM_PK
 #define SFM_PK 1                       // 1: the fused tick's planar systolic step on packed fp32 instructions (A/B, round 4)
 #endif
 
 #include <algorithm>
+#include <type_traits>
 #include <cstdlib>
 
 namespace sfm {
@@ -298,6 +302,51 @@ __device__ __forceinline__ bool moussaid_planar_pk(const IxConst& c, v2f pj, v2f
     asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[0,0] neg_lo:[0,1]" : "=v"(B) : "v"(gv), "v"(t));
     term = __builtin_elementwise_fma(bcast(e1), t, B);                 // (e1 tx - g ty, e1 ty + g tx)
     return true;
+}
+
+// TWO pairs per lane (round 4, the fused tick's planar step without use_ped_radius): the lane's resident pedestrian against two
+// travelling ones at once, every quantity a register pair {pair A, pair B}, so that ALL of the body's full-rate arithmetic issues as
+// packed instructions -- 41 v_pk_*_f32, 6 v_bfi, 10 transcendentals and 4 v_add_f32_dpp per TWO pairs instead of 2 x 41 instructions
+// (the x / y packing above only reaches the 20 operations that come in x / y pairs).  Same operations on the same operands per pair
+// as moussaid_planar<false, false>; only the order in which a pedestrian's terms are summed changes (two travelling chains per wave).
+__device__ __forceinline__ v2f rsq2(v2f v) { v2f r; r.x = rsq(v.x); r.y = rsq(v.y); return r; }
+__device__ __forceinline__ v2f rcp2(v2f v) { v2f r; r.x = rcp(v.x); r.y = rcp(v.y); return r; }
+__device__ __forceinline__ v2f ex22(v2f v) { v2f r; r.x = ex2(v.x); r.y = ex2(v.y); return r; }
+__device__ __forceinline__ v2f copysign2(v2f m, v2f sg) { v2f r; r.x = copysignf(m.x, sg.x); r.y = copysignf(m.y, sg.y); return r; }
+__device__ __forceinline__ v2f fma2(v2f a_, v2f b_, v2f c_) { return __builtin_elementwise_fma(a_, b_, c_); }
+__device__ __forceinline__ void moussaid_planar_x2(const IxConst& c, float pjx, float pjy, float ujx, float ujy, v2f X, v2f Y, v2f U, v2f V,
+                                                   v2f& cx, v2f& cy) {
+    const v2f dx = bcast(pjx) - X, dy = bcast(pjy) - Y;                // other - self, pairs A and B
+    const v2f d2 = fma2(dx, dx, dy * dy);
+    const v2f rinv = rsq2(d2);
+    const v2f d = d2 * rinv;
+    const v2f Dx = fma2(dx, rinv, U - bcast(ujx)), Dy = fma2(dy, rinv, V - bcast(ujy));     // D = e + lambda (v_i - v_j)
+    const v2f D2 = fma2(Dx, Dx, fma2(Dy, Dy, bcast(TINY)));
+    const v2f rD = rsq2(D2);
+    const v2f aL = d * (rD * bcast(c.c1));
+    const v2f Dn = D2 * rD;                                            // |D|
+    const v2f tx = Dx * rD, ty = Dy * rD;
+    const v2f S = fma2(tx, dy, -(ty * dx)), C = fma2(tx, dx, ty * dy); // d sin, d cos of angle(e) - angle(t)
+    // half_angle_theta, both pairs (forces.py:94,101)
+    const v2f sc = copysign2(bcast(1.0f), C);
+    const v2f r = S * rcp2(fma2(sc, d, C));
+    const v2f z = r * r;
+    v2f p = bcast(-0.0095607885413262813f);
+    p = fma2(p, z, bcast(0.049113825228842972f));
+    p = fma2(p, z, bcast(-0.11980885478692463f));
+    p = fma2(p, z, bcast(0.1988547939908939f));
+    p = fma2(p, z, bcast(-0.28058826128196529f));
+    p = fma2(p, z, bcast(0.39942748114880167f));
+    p = fma2(p, z, bcast(-0.66664186893326649f));
+    p = fma2(p, z, bcast(1.9999998228145017f));
+    const v2f h = copysign2(bcast(1.57079632679489662f), S);
+    const v2f theta = fma2(p, r, fma2(bcast(-c.eg), Dn, fma2(-sc, h, h)));
+    const v2f q = Dn * theta;
+    const v2f q2 = q * q;
+    const v2f e1 = ex22(fma2(q2, bcast(c.k1), aL)), e2 = ex22(fma2(q2, bcast(c.k2), aL));
+    const v2f g = copysign2(e2, theta);
+    cx = fma2(e1, tx, -(g * ty));
+    cy = fma2(e1, ty, g * tx);
 }
 
 // The same for a 3-D crowd (round 3; pedestrian_state.py:17-19 keeps 3-component positions and velocities and forces.py:75-117
@@ -2194,7 +2243,9 @@ struct FusedShared {                             // LDS of one pair-role workgro
     int any;
     float2 fi[NW][WAVE];
     float2 fj[NW][WAVE];
-    float4 trav[4][2 * WAVE];                    // the four tiles as travelling operands, each twice back to back
+    float2 fi2[(SFM_X2 && !RAD && !Z3) ? NW : 1][WAVE];   // two pairs per lane: the sums of a wave's second travelling chain
+    float4 trav[4][2 * WAVE];                    // the four tiles as travelling operands, each twice back to back (two pairs per lane: as four
+                                                 // planes x, y, lambda vx, lambda vy of [4][2 * WAVE] floats -- a lane reads its two pedestrians' x as one ds_read2_b32)
     float radt[RAD ? 4 : 1][2 * WAVE];
     float2 stz[Z3 ? 2 * GROUP : 1];              // 3-D crowds: {z, vz} of the same pedestrians ...
     float2 travz[Z3 ? 4 : 1][2 * WAVE];          // ... {z, lambda vz} as travelling operands
@@ -2220,6 +2271,7 @@ __global__ __launch_bounds__(NW * WAVE, (NW == 8 && Z3) ? 6 : 8) void sfm_fused_
     constexpr int PARTS = NW / 2;                // the slab rows are split over this many 128-thread parts
     constexpr int SPW = 4 * WAVE / NW;           // systolic steps per wave
     constexpr int D = NW / 8;                    // waves per diagonal tile
+    constexpr bool X2 = SFM_X2 && !RAD && !Z3;   // two pairs per lane (moussaid_planar_x2)
     using Sh = FusedShared<RAD, NW, Z3>;
     constexpr size_t LDS = (GEO && sizeof(GeoShared<NW>) > sizeof(Sh)) ? sizeof(GeoShared<NW>) : sizeof(Sh);
     __shared__ __attribute__((aligned(16))) char smem[LDS];
@@ -2391,8 +2443,16 @@ __global__ __launch_bounds__(NW * WAVE, (NW == 8 && Z3) ? 6 : 8) void sfm_fused_
     auto put_state = [&](const float4 ns, const float2 nsz) {   // pedestrian slot p of the workgroup in the state the pairs are evaluated on
         sh.st[p] = ns;
         const float4 t = make_float4(ns.x, ns.y, a.ped.lam * ns.z, a.ped.lam * ns.w);
+        if (X2) {
+            float* pl = reinterpret_cast<float*>(sh.trav) + (p >> 6) * 2 * WAVE + (p & (WAVE - 1));      // plane c at + c * 4 * 2 * WAVE
+            pl[0] = t.x; pl[WAVE] = t.x;
+            pl[8 * WAVE] = t.y; pl[9 * WAVE] = t.y;
+            pl[16 * WAVE] = t.z; pl[17 * WAVE] = t.z;
+            pl[24 * WAVE] = t.w; pl[25 * WAVE] = t.w;
+        } else {
         sh.trav[p >> 6][p & (WAVE - 1)] = t;
         sh.trav[p >> 6][(p & (WAVE - 1)) + WAVE] = t;
+        }
         if (Z3) {
             sh.stz[Z3 ? p : 0] = nsz;
             const float2 tz = make_float2(nsz.x, a.ped.lam * nsz.y);
@@ -2545,6 +2605,51 @@ __global__ __launch_bounds__(NW * WAVE, (NW == 8 && Z3) ? 6 : 8) void sfm_fused_
     }
     float fxi = 0.f, fyi = 0.f, fxj = 0.f, fyj = 0.f, fzi = 0.f, fzj = 0.f;
     int i_end_loc = lane;
+    float fxb = 0.f, fyb = 0.f;                   // X2: the sums of the second travelling chain, and where they end up
+    int i_end_b = lane;
+    if (X2 && work) {
+        // Two pairs per lane: the wave's SPW steps are SPW / 2 double steps; chain A meets sigma0 .. sigma0 + SPW/2 - 1, chain B the same
+        // XB further on -- half a tile pair (32) away, on a diagonal tile half of ITS 32 rotations (16) -- so the waves of a tile pair
+        // still cover every rotation once.  A lane's two travelling pedestrians are XB slots apart in the doubled image: one
+        // ds_read2_b32 per plane brings both into a register pair.
+        const IxConst& c = a.ped;
+        const float4 pj = sh.st[ib + lane];
+        const float ujx = c.lam * pj.z, ujy = c.lam * pj.w;
+        constexpr int HALF = SPW / 2;
+        const int s0 = diag ? 1 + ((sig0 - 1) >> 1) : sig0 >> 1;      // (sig0 was laid out for SPW steps per wave: 1 + j SPW / j SPW)
+        const float* pl = reinterpret_cast<const float*>(sh.trav) + (ia >> 6) * 2 * WAVE + lane + s0;
+        v2f fjx = bcast(0.f), fjy = bcast(0.f);
+        auto chain = [&](auto xb_tag) __attribute__((always_inline)) {
+            constexpr int XB = decltype(xb_tag)::value;
+            const bool tail_one_sided = diag && (s0 + XB + HALF - 1 == 32);       // sigma = 32 on a diagonal tile: one-sided (uniform)
+            v2f X, Y, U, V;
+            X.x = pl[0]; X.y = pl[XB]; Y.x = pl[8 * WAVE]; Y.y = pl[8 * WAVE + XB];
+            U.x = pl[16 * WAVE]; U.y = pl[16 * WAVE + XB]; V.x = pl[24 * WAVE]; V.y = pl[24 * WAVE + XB];
+#pragma unroll
+            for (int s_ = 0; s_ < HALF; ++s_) {
+                v2f Xn = X, Yn = Y, Un = U, Vn = V;
+                if (s_ + 1 < HALF) {                                  // the next double step's operands are in flight during this one
+                    Xn.x = pl[s_ + 1]; Xn.y = pl[s_ + 1 + XB]; Yn.x = pl[8 * WAVE + s_ + 1]; Yn.y = pl[8 * WAVE + s_ + 1 + XB];
+                    Un.x = pl[16 * WAVE + s_ + 1]; Un.y = pl[16 * WAVE + s_ + 1 + XB]; Vn.x = pl[24 * WAVE + s_ + 1]; Vn.y = pl[24 * WAVE + s_ + 1 + XB];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                v2f cx, cy;
+                moussaid_planar_x2(c, pj.x, pj.y, ujx, ujy, X, Y, U, V, cx, cy);
+                fxi = rot_in(fxi) + cx.x; fyi = rot_in(fyi) + cy.x;
+                fxb = rot_in(fxb) + cx.y; fyb = rot_in(fyb) + cy.y;
+                if (s_ + 1 == HALF && tail_one_sided) { fjx.x -= cx.x; fjy.x -= cy.x; }      // (chain B's last pair: the travelling side only)
+                else { fjx -= cx; fjy -= cy; }
+                X = Xn; Y = Yn; U = Un; V = Vn;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            i_end_loc = (lane + s0 + HALF - 1) & (WAVE - 1);
+            i_end_b = (lane + s0 + XB + HALF - 1) & (WAVE - 1);
+        };
+        if (diag) chain(std::integral_constant<int, 16>{});
+        else chain(std::integral_constant<int, 32>{});
+        fxj = fjx.x + fjx.y;
+        fyj = fjy.x + fjy.y;
+    } else
     if (work) {
         const IxConst& c = a.ped;
         const float4 pj = sh.st[ib + lane];
@@ -2607,6 +2712,7 @@ __global__ __launch_bounds__(NW * WAVE, (NW == 8 && Z3) ? 6 : 8) void sfm_fused_
     }
     FUSED_WAVE_STAMP(0);
     sh.fi[wave][i_end_loc] = make_float2(fxi, fyi);
+    if (X2) sh.fi2[X2 ? wave : 0][i_end_b] = make_float2(fxb, fyb);
     sh.fj[wave][lane] = make_float2(fxj, fyj);
     if (Z3) { sh.fiz[Z3 ? wave : 0][i_end_loc] = fzi; sh.fjz[Z3 ? wave : 0][lane] = fzj; }
     FUSED_STAMP(3);
@@ -2615,7 +2721,11 @@ __global__ __launch_bounds__(NW * WAVE, (NW == 8 && Z3) ? 6 : 8) void sfm_fused_
     if (!lower || !present) return;
     const int tl = (p >> 6) & 1, l = lane;       // tile of the group, pedestrian of the tile
     // sums of wave w for pedestrian l of its travelling / resident tile, z in the third component
-    auto fi = [&](int w) { const float2 v = sh.fi[w][l]; return make_float3(v.x, v.y, Z3 ? sh.fiz[Z3 ? w : 0][l] : 0.f); };
+    auto fi = [&](int w) {
+        float2 v = sh.fi[w][l];
+        if (X2) { const float2 v2 = sh.fi2[X2 ? w : 0][l]; v.x += v2.x; v.y += v2.y; }       // (both travelling chains of the wave)
+        return make_float3(v.x, v.y, Z3 ? sh.fiz[Z3 ? w : 0][l] : 0.f);
+    };
     auto fj = [&](int w) { const float2 v = sh.fj[w][l]; return make_float3(v.x, v.y, Z3 ? sh.fjz[Z3 ? w : 0][l] : 0.f); };
     float3 r = make_float3(0.f, 0.f, 0.f);
     int row;                                     // partner group = slab row
