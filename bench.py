@@ -26,7 +26,7 @@ Workloads (--workload overrides the default, and the SAME 
 
 Roofline record.  The dominant kernel is the pedestrian-pair kernel.  Its binding resource is VALU issue (DESIGN.md
 3.6): `roofline.bound = "valu_issue"`, achieved = VALU wave-instructions per launch (SQ_INSTS_VALU, mean per launch from
-the rocprofv3 --pmc passes summarised in profiles/r03_pmc_summary.csv, a tracked file whose header carries the git blob id of
+the rocprofv3 --pmc passes summarised in profiles/r04_pmc_summary.csv, a tracked file whose header carries the git blob id of
 sfm_kernels.hip at collection time: `roofline.counters_stale` says whether the loaded build differs) / the kernel's own launch
 duration measured live with HIP events on the launch stream, against 1024 SIMDs x 0.5 wave-instr/clk x 2.4 GHz.
 `roofline.hbm_algorithmic` keeps SURVEY.md 8d's yardstick (16 B per ordered pair / launch time against 8 TB/s) and
@@ -48,7 +48,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak
 SIMDS, CLOCK_HZ = 1024, 2.4e9
 VALU_PEAK_GINSTR = SIMDS * 0.5 * CLOCK_HZ / 1e9     # v_fma_f32 (wave64): 2 cycles per SIMD (MI355X_MICROARCH.md, cycle constants)
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03_pmc_summary.csv")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r04_pmc_summary.csv")
 KERNEL_SOURCE = os.path.join(ROOT, "carla-social-force-model_amd", "csrc", "sfm_kernels.hip")   # beside the loaded libsfm_hip.so
 # The counter passes (tools/pmc_run.sh -> tools/pmc_ticks.py) run this many ticks from the uploaded scenario.  With a cutoff the
 # pair kernel's instruction count depends on where the crowd has got to, so the launch duration that goes with those
@@ -308,8 +308,12 @@ def main():
         raise SystemExit(f"bench.py: state check failed after the timed run on rank {rank} (non-finite or over-speed pedestrians)")
 
     # whole tick on the launch stream (HIP events, no collective in between) ...
-    eng.engine.set_timing(True)
     reps = min(max(args.steps, 1), 200 if sc.n <= 16384 else 10)
+    if world == 1:
+        # (the state check above left the GPU idle for a moment: a few hundred untimed ticks first, so that the event-timed run and the
+        #  profiled launches behind `roofline` see the clocks the timed windows saw -- round 4: without them a 200-tick burst read 7 % slow)
+        eng.engine.run(max(3 * reps, 600 if sc.n <= 16384 else 0), redraw=True)
+    eng.engine.set_timing(True)
     # (a rank of a sharded run gets no exchange here: one tick only, so that the other ranks' rows it reads are one tick old at most)
     eng.engine.run(reps if world == 1 else 1, redraw=True)
     ev_ms, ev_ticks, ev_launches = eng.engine.timing()

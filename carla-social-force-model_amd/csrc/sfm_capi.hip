@@ -157,6 +157,7 @@ struct SfmHandle {
     int part_gx = 0, part_gy = 0;
     std::vector<int> part_bounds;               // [gx*gy + 1] row bounds (empty: equal split of the padded row count)
     int resort_every = 64, ticks_since_sort = 0;
+    bool resort_every_set = false;              // SFM_RESORT_EVERY given: every path re-packs at exactly that period
     bool perm_stale = false;
     float r_max = 0.f;
     bool used_sym = false;
@@ -384,7 +385,7 @@ int sfm_create(const SfmParams* params, int device_id, SfmHandle** out) {
     ov = exp_env("SFM_DEBUG_STEPS");
     if (ov) h->debug_steps = atoi(ov);
     ov = getenv("SFM_RESORT_EVERY");
-    if (ov) h->resort_every = atoi(ov);
+    if (ov) { h->resort_every = atoi(ov); h->resort_every_set = true; }
     if (exp_env("SFM_STAMPS")) {
         if (hipMalloc(reinterpret_cast<void**>(&h->stamps), sizeof(unsigned long long) * 3 * PAIR_STAMP_WGS) != hipSuccess) h->stamps = nullptr;
         else {
@@ -1261,7 +1262,11 @@ static int run_fused(SfmHandle* h, int ticks, uint32_t flags, bool carry, bool g
     bool front = !carry;
     int launches = 0;
     for (int t = 0; t < ticks && rc == SFM_OK; ++t) {
-        if (geo && h->reordered && h->resort_every > 0 && h->ticks_since_sort >= h->resort_every) {
+        // (only the border / obstacle culls care how compact a tile is here -- no tile-pair list below the cutoff -- and they degrade
+        //  slowly: all forces at N = 2048 / 4096, 2000 ticks: 11.3 / 19.5 us per tick re-packing every 64 ticks, 11.0 / 18.8 every 128,
+        //  10.8 / 18.5 every 256, 10.7 / 18.5 every 512 -- so this path re-packs every 256 ticks unless SFM_RESORT_EVERY says otherwise)
+        const int period = h->resort_every_set ? h->resort_every : 4 * h->resort_every;
+        if (geo && h->reordered && period > 0 && h->ticks_since_sort >= period) {
             rc = resort_rows(h);
             if (rc) return rc;
             launches += 5;
