@@ -368,6 +368,15 @@ def main():
             roof["valu_instructions_per_64_pair_step"] = insts / (pair_terms / 64.0)
         if "SQ_WAIT_INST_ANY" in pmc and "SQ_WAVE_CYCLES" in pmc and pmc["SQ_WAVE_CYCLES"] > 0:
             roof["wait_inst_any_over_wave_cycles"] = pmc["SQ_WAIT_INST_ANY"] / pmc["SQ_WAVE_CYCLES"]
+        if "SQ_ACTIVE_INST_VALU" in pmc and pmc.get("GRBM_GUI_ACTIVE", 0) > 0:
+            # Round 4: the packed step makes ONE instruction of two, so the plain count above falls while the kernel gets faster.  What
+            # the counters say about the pipes themselves: cycles a VALU instruction was executing (SQ_ACTIVE_INST_VALU, in units of four
+            # cycles) over the SIMD-cycles of the launch (GRBM_GUI_ACTIVE is summed over the 8 XCDs) -- both from the same counter pass.
+            roof["valu_busy_frac"] = 4.0 * pmc["SQ_ACTIVE_INST_VALU"] / (SIMDS * pmc["GRBM_GUI_ACTIVE"] / 8.0)
+            roof["valu_busy_definition"] = "4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs), counter pass only"
+        mix = {k: pmc[k] for k in ("SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_TRANS_F32") if k in pmc}
+        if mix:
+            roof["fp32_instruction_mix_per_launch"] = mix
         if sc.n < 256:
             # a crowd of one tile: ONE launch per tick of a handful of workgroups (the fused tick: a pair workgroup, its geometry
             # workgroups, the vehicles).  Nothing on the chip is busy; what the tick costs is the launch and the geometry workgroup's
@@ -397,6 +406,12 @@ def main():
     roof.update(stamp)
     if roof.get("frac") is not None and roof["bound"] == "valu_issue" and roof["frac"] > 1.0:      # never publish a non-physical fraction
         roof.update({"frac": None, "note": (roof.get("note", "") + " [fraction above 1 withheld: counters do not belong to this build]").strip()})
+    if world == 1 and sc.n > 4096 and roof.get("frac") is not None:
+        # (state-dependent workloads: say what the fraction is a fraction OF -- round-3 verdict, bench hygiene)
+        roof["frac_scope"] = ("pair kernel ALONE (no border / obstacle workgroups in its launch: the counter passes run with SFM_PAIR_GEO=0 and "
+                              "sfm_profile_dominant_kernel launches sfm_pair_sym_kernel by itself), at the state of the counter passes -- "
+                              f"{PMC_STATE_TICKS[name]} ticks after the upload; ms_per_step is the median window of the whole timed run, whose "
+                              "crowd moves on (kernel_us_end_of_run)")
     roof.update({"kernel": dominant, "kernel_variant": variant, "kernel_us": kernel_us, "kernel_us_state": state_note,
                  "kernel_us_end_of_run": kernel_us_end, "tick_us": tick_us,
                  "launches_per_tick": ev_launches / max(ev_ticks, 1), "algorithmic_bytes_per_tick": alg_tick})

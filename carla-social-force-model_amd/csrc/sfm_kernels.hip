@@ -384,6 +384,49 @@ __device__ __forceinline__ bool moussaid_spatial(const IxConst& c, float dx, flo
     return true;
 }
 
+// The 3-D body with its x / y pairs on packed fp32 instructions (round 4; the z components stay scalar): the drop-in CARLA path is a
+// 3-D crowd (pedestrian_state.py:17-19 -- walkers never have exactly equal z), so this is the step real callers run.  Same operations
+// on the same operands as moussaid_spatial, hence the same bits.  d2 comes out of here (3-D squared distance), reach2 as in the planar form.
+template <bool RAD, bool CUT>
+__device__ __forceinline__ bool moussaid_spatial_pk(const IxConst& c, v2f pj, float zj, v2f uj, float ujz, v2f Ti, float zi, v2f Ui, float uiz,
+                                                    float rsum, float reach2, v2f& term, float& cz) {
+    const v2f dd = pj - Ti;                                            // (dx, dy) = other - self
+    const float dz = zj - zi;
+    const float d2 = fmaf(dd.x, dd.x, fmaf(dd.y, dd.y, dz * dz));
+    if (CUT && !__any(!(d2 > reach2))) return false;
+    const float rinv = rsq(d2);
+    const float d = d2 * rinv;
+    const v2f Dv = __builtin_elementwise_fma(dd, bcast(rinv), Ui - uj);  // D = e + lambda (v_i - v_j)
+    const float Dz = fmaf(dz, rinv, uiz - ujz);
+    const float D2 = fmaf(Dv.x, Dv.x, fmaf(Dv.y, Dv.y, fmaf(Dz, Dz, TINY)));
+    const float rD = rsq(D2);
+    const float deff = RAD ? d - rsum : d;
+    const float aL = deff * (rD * c.c1);
+    if (CUT && !__any(!(aL <= -41.0f))) return false;
+    const float Dn = D2 * rD;                                          // |D|
+    const v2f t = Dv * bcast(rD);
+    const float tz = Dz * rD;
+    const v2f A = bcast(t.x) * __builtin_shufflevector(dd, dd, 1, 0);  // (tx dy, tx dx)
+    v2f SC;                                                            // (S, C) = (tx dy - ty dx, tx dx + ty dy): |t_xy| |d_xy| (sin, cos)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1] neg_lo:[0,1,0]" : "=v"(SC) : "v"(t), "v"(dd), "v"(A));
+    const float h2 = fmaf(SC.x, SC.x, SC.y * SC.y);
+    const float h = h2 * rsq(h2);
+    const float theta = half_angle_theta(SC.x, SC.y, h, c.eg, Dn);    // forces.py:94,101
+    const float q = Dn * theta;
+    const float q2 = q * q;
+    v2f kk; kk.x = c.k1; kk.y = c.k2;
+    const v2f arg = __builtin_elementwise_fma(bcast(q2), kk, bcast(aL));
+    const float e1 = ex2(arg.x);
+    const float e2 = ex2(arg.y);
+    const float g = copysignf(e2, theta);
+    v2f gv; gv.x = g;
+    v2f B;                                                             // (-g ty, g tx)
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[0,0] neg_lo:[0,1]" : "=v"(B) : "v"(gv), "v"(t));
+    term = __builtin_elementwise_fma(bcast(e1), t, B);                 // (e1 tx - g ty, e1 ty + g tx)
+    cz = e1 * tz;
+    return true;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
@@ -1689,17 +1732,21 @@ __device__ __forceinline__ void pair_block(const float4* __restrict__ pk, const 
             __builtin_amdgcn_sched_barrier(0);
             bool done = false;
 #if SFM_PK
-            if (!Z3) {                            // planar crowds: the step on packed fp32 instructions (round 4)
+            {                                     // the step on packed fp32 instructions (round 4): x / y pairs packed, z scalar
                 v2f pjv, ujv, Tv, Uv, cv;
+                float cz = 0.f;
                 pjv.x = pj.x; pjv.y = pj.y; ujv.x = ujx; ujv.y = ujy; Tv.x = T.x; Tv.y = T.y; Uv.x = T.z; Uv.y = T.w;
-                if (moussaid_planar_pk<RAD, CUT>(c, pjv, ujv, Tv, Uv, RAD ? ri + rj : 0.f, reach2, cv)) {
+                const bool kept = Z3 ? moussaid_spatial_pk<RAD, CUT>(c, pjv, zj, ujv, ujz, Tv, Tz.x, Uv, Tz.y, RAD ? ri + rj : 0.f, reach2, cv, cz)
+                                     : moussaid_planar_pk<RAD, CUT>(c, pjv, ujv, Tv, Uv, RAD ? ri + rj : 0.f, reach2, cv);
+                if (kept) {
                     fxi = rot_in(fxi) + cv.x;
                     fyi = rot_in(fyi) + cv.y;
-                    if (s_ < one_sided_from) fjv -= cv;
+                    if (Z3) fzi = rot_in(fzi) + cz;
+                    if (s_ < one_sided_from) { fjv -= cv; if (Z3) fzj -= cz; }
                     done = true;
                 }
-            } else
-#endif
+            }
+#else
             {
             const float dx = pj.x - T.x, dy = pj.y - T.y;
             const float dz = Z3 ? zj - Tz.x : 0.f;
@@ -1718,6 +1765,7 @@ __device__ __forceinline__ void pair_block(const float4* __restrict__ pk, const 
                 }
             }
             }
+#endif
             if (CUT && !done) { fxi = rot_in(fxi); fyi = rot_in(fyi); if (Z3) fzi = rot_in(fzi); }
             T = Tn;
             ri = rin;
@@ -1732,7 +1780,7 @@ __device__ __forceinline__ void pair_block(const float4* __restrict__ pk, const 
             for (int s_ = 0; s_ < nsteps; ++s_) step(s_);
         }
         i_end_loc = (lane + sig0 + nsteps - 1) & (WAVE - 1);
-        if (SFM_PK && !Z3) { fxj = fjv.x; fyj = fjv.y; }
+        if (SFM_PK) { fxj = fjv.x; fyj = fjv.y; }
       }
     }
     sh.fi[wave][i_end_loc] = make_float2(fxi, fyi);
@@ -2680,7 +2728,12 @@ __global__ __launch_bounds__(NW * WAVE, (NW == 8 && Z3) ? 6 : 8) void sfm_fused_
             __builtin_amdgcn_sched_barrier(0);       // (... so its read is issued here, not where the scheduler would sink it to)
             const float dx = pj.x - T.x, dy = pj.y - T.y;
             float cx, cy, cz = 0.f;
-            if (Z3) {
+            if (Z3 && SFM_PK) {
+                v2f pjv, ujv, Tv, Uv, cv;
+                pjv.x = pj.x; pjv.y = pj.y; ujv.x = ujx; ujv.y = ujy; Tv.x = T.x; Tv.y = T.y; Uv.x = T.z; Uv.y = T.w;
+                moussaid_spatial_pk<RAD, false>(c, pjv, zj, ujv, ujz, Tv, Tz.x, Uv, Tz.y, RAD ? ri + rj : 0.f, 0.f, cv, cz);
+                cx = cv.x; cy = cv.y;
+            } else if (Z3) {
                 const float dz = zj - Tz.x;
                 moussaid_spatial<RAD, false>(c, dx, dy, dz, fmaf(dx, dx, fmaf(dy, dy, dz * dz)), T.z - ujx, T.w - ujy, Tz.y - ujz, RAD ? ri + rj : 0.f, cx, cy, cz);
             } else {

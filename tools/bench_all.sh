@@ -4,9 +4,9 @@ tag=${1:-run}
 out=$GRAFT_REPO_ROOT/gpurun_out
 cd $GRAFT_REPO_ROOT
 for w in c1 c2 c3 c4 c5; do
-  extra="--no-cpu-baseline"; [ $w = c2 ] && extra=""
+  extra=""; [ $w = c4 ] && extra="--no-cpu-baseline"      # (c1, c2, c3, c5 carry cpu_baseline; c4's crowd disperses, its line is a state-dependent curiosity)
   steps=2000; [ $w = c4 ] && steps=1000; [ $w = c5 ] && steps=300
-  timeout -k 10 400 python bench.py --workload $w --steps $steps --warmup 100 $extra > $out/${tag}_bench_$w.json 2> $out/${tag}_bench_$w.err || exit 1
+  timeout -k 10 600 python bench.py --workload $w --steps $steps --warmup 100 $extra > $out/${tag}_bench_$w.json 2> $out/${tag}_bench_$w.err || exit 1
   python3 -c "
 import json,sys
 d=json.load(open('$out/${tag}_bench_$w.json')); r=d['roofline']

@@ -1,8 +1,8 @@
 #!/bin/bash
 # One gpurun call that produces the round's judged artefacts with ONE build: counter passes -> profiles/<tag>_pmc_summary.csv (on the
 # box, so that the bench lines read it), the five bench lines, kernel-trace stats of the same bench command.
-#   bash tools/final_round.sh r03      (inside gpurun; copy gpurun_out/<tag>_* into profiles/ afterwards)
-tag=${1:-r03}
+#   bash tools/final_round.sh r04      (inside gpurun; copy gpurun_out/<tag>_* into profiles/ afterwards)
+tag=${1:-r04}
 root=$GRAFT_REPO_ROOT
 out=$root/gpurun_out
 bash $root/tools/pmc_run.sh $tag c1 c2 c3 c4 c5 || exit 1
