@@ -368,15 +368,30 @@ def main():
             roof["valu_instructions_per_64_pair_step"] = insts / (pair_terms / 64.0)
         if "SQ_WAIT_INST_ANY" in pmc and "SQ_WAVE_CYCLES" in pmc and pmc["SQ_WAVE_CYCLES"] > 0:
             roof["wait_inst_any_over_wave_cycles"] = pmc["SQ_WAIT_INST_ANY"] / pmc["SQ_WAVE_CYCLES"]
-        if "SQ_ACTIVE_INST_VALU" in pmc and pmc.get("GRBM_GUI_ACTIVE", 0) > 0:
-            # Round 4: the packed step makes ONE instruction of two, so the plain count above falls while the kernel gets faster.  What
-            # the counters say about the pipes themselves: cycles a VALU instruction was executing (SQ_ACTIVE_INST_VALU, in units of four
-            # cycles) over the SIMD-cycles of the launch (GRBM_GUI_ACTIVE is summed over the 8 XCDs) -- both from the same counter pass.
-            roof["valu_busy_frac"] = 4.0 * pmc["SQ_ACTIVE_INST_VALU"] / (SIMDS * pmc["GRBM_GUI_ACTIVE"] / 8.0)
-            roof["valu_busy_definition"] = "4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs), counter pass only"
         mix = {k: pmc[k] for k in ("SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_TRANS_F32") if k in pmc}
         if mix:
             roof["fp32_instruction_mix_per_launch"] = mix
+        if fused and pair_terms and name == "c2":
+            # Round 4: the packed step makes ONE instruction of two, so the plain count above FALLS while the kernel gets faster (8.66 M
+            # wave-instructions per launch in round 3, 5.10 M now).  The pipes are busy for PASSES of 2 cycles: 1 per full-rate fp32
+            # instruction, 2 per packed (v_pk_*_f32) or "other" (v_bfi, v_add_f32_dpp) instruction, 4 per transcendental (MI355X_MICROARCH.md
+            # cycle table; tools/valu_microbench.hip).  Packed and other instructions of the loop are counted from its ISA (41 and 10 per
+            # 128-pair double step, `make asm`), transcendentals by SQ_INSTS_VALU_TRANS_F32 (10 per double step if that pass is missing).
+            dsteps = pair_terms / 128.0
+            trans = pmc.get("SQ_INSTS_VALU_TRANS_F32", 10.0 * dsteps)
+            # `frac` itself: fp32 wave-OPERATIONS per second against the 2-cycle rate -- a packed instruction is two operations (and takes
+            # the pipe for two passes), so this is the round-3 definition carried over (every instruction was one operation then: 0.43)
+            ops = insts + 41.0 * dsteps
+            roof.update({"frac_plain_instructions": roof["frac"], "achieved_plain_instructions": roof["achieved"],
+                         "achieved": ops / (kernel_us * 1e-6) / 1e9, "frac": ops / (kernel_us * 1e-6) / 1e9 / VALU_PEAK_GINSTR,
+                         "unit": "G fp32 wave-operations/s", "valu_wave_operations_per_launch": ops,
+                         "achieved_definition": "(SQ_INSTS_VALU + packed instructions: each v_pk_*_f32 is two wave-wide fp32 operations; 41 per 128-pair "
+                                                "double step of the loop, from its ISA) per launch / kernel_us"})
+            passes = insts + 41.0 * dsteps + 10.0 * dsteps + 3.0 * trans
+            roof["class_weighted"] = {"issue_passes_per_launch": passes, "achieved": passes / (kernel_us * 1e-6) / 1e9, "peak": VALU_PEAK_GINSTR,
+                                      "unit": "G two-cycle passes/s", "frac": passes / (kernel_us * 1e-6) / 1e9 / VALU_PEAK_GINSTR,
+                                      "definition": "SQ_INSTS_VALU + packed + other + 3 x transcendental instructions per launch / kernel_us "
+                                                    "against 1024 SIMDs x 2.4 GHz / 2"}
         if sc.n < 256:
             # a crowd of one tile: ONE launch per tick of a handful of workgroups (the fused tick: a pair workgroup, its geometry
             # workgroups, the vehicles).  Nothing on the chip is busy; what the tick costs is the launch and the geometry workgroup's
