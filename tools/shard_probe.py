@@ -5,10 +5,11 @@ is replayed by sfm_set_shard(rows of r).  No collective here -- this is the comp
 
 For every G (a fresh handle each): the equal split, then `PROBE_ITER` rounds of stepper.balanced_bounds on the engine's work
 measure, each followed by the re-pack that cuts the blocks at the new boundaries (what ShardedStepper does at each re-pack).
-Prints per-rank tick time (HIP events, mean of 3 ticks), the max over ranks and the strong-scaling bound
+Prints per-rank tick time (wall clock over PROBE_REPS = 40 ticks, the library's per-call event bracket off), the max over ranks and the strong-scaling bound
 t(G=1) / max_r t_r(G) that the compute alone allows."""
 import os
 import sys
+import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -17,6 +18,7 @@ from carla_social_force_model_amd.config import default_sfm_config              
 from carla_social_force_model_amd.stepper import HipShardEngine, balanced_bounds, block_layout, equal_bounds   # noqa: E402
 
 ITER = int(os.environ.get("PROBE_ITER", "3"))
+REPS = int(os.environ.get("PROBE_REPS", "40"))
 name = sys.argv[1] if len(sys.argv) > 1 else "c5"
 Gs = [int(a) for a in sys.argv[2:]] or [1, 2, 4, 8]
 sc, forces = scenarios.baseline_scenario(name)
@@ -31,15 +33,21 @@ for G in Gs:
 
     def measure(lo, hi):
         e.set_shard(lo, hi)
+        e.set_timing(True)
         e.tick()                                  # settles the launch shape / lists for this shard (state not advanced)
         e.tick(); e.tick(); e.tick()
         eng.synchronize()
-        t = []
-        for _ in range(3):
+        _, k, l = e.timing()
+        # wall clock over REPS ticks with the library's own HIP-event bracket of every call switched off (round 4: the bracket is two event
+        # records, ~10 us per tick -- 15 % of a c4 rank's tick -- and no real run has it on: bench.py and the stepper switch it off too)
+        e.set_timing(False)
+        e.tick(); eng.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(REPS):
             e.tick()
-            ms, k, l = e.timing()
-            t.append(ms / k * 1e3)
-        return sum(t) / len(t), l / k, eng.work(), e.pair_work()[1]
+        eng.synchronize()
+        us = (time.perf_counter() - t0) / REPS * 1e6
+        return us, l / k, eng.work(), e.pair_work()[1]
 
     b = equal_bounds(n, n_pad, G)
     for it in range(ITER + 1 if G > 1 else 1):
