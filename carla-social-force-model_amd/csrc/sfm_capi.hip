@@ -37,7 +37,7 @@ hipError_t launch_resort_blocks(const float4* pk, int N, const BlockPlan& pl, co
 hipError_t launch_unpack_geo(const char* block, float4* ctr, int K, float2* pts, int P, int* off, bool with_off, hipStream_t st);
 hipError_t launch_unpack_rows(const char* block, size_t b_own, size_t b_zv, size_t b_rr, size_t b_cm, int n_pad, float4* pk0,
                               float4* pk1, float4* own, float2* zv0, float2* zv1, float* radius, uint8_t* crossing, uint32_t* draws,
-                              hipStream_t st);
+                              const char* geo_block, float4* ctr, int K, float2* pts, int P, int* off, bool with_off, hipStream_t st);
 hipError_t launch_gather(const uint32_t* src, int N, const float4* pk_in, float4* pk_out, const float2* zv_in, float2* zv_out,
                          const float4* own_in, float4* own_out, const float* rad_in, float* rad_out, const uint8_t* cr_in,
                          uint8_t* cr_out, const uint32_t* dr_in, uint32_t* dr_out, const uint32_t* id_in, uint32_t* id_out,
@@ -66,6 +66,8 @@ struct DevGeo {
     char* stage = nullptr;                              // pinned host block the three arrays are copied from, asynchronously
     size_t stage_cap = 0;
     std::vector<int> off_host;                          // the offsets the device holds (vehicles arrive every tick with the same ring sizes: not copied again)
+    bool lazy = false;                                  // the staged block has not been spread over the device arrays yet: the next state upload's
+    bool lazy_off = false;                              // unpack launch takes it along (flush_lazy_geo for everything else that reads the arrays)
 };
 
 struct SfmHandle {
@@ -521,13 +523,13 @@ int sfm_set_stream(SfmHandle* h, void* hip_stream) {
 
 // Upload one CSR geometry set. ctr4 holds the 4 floats per polyline the kernels want.
 static int set_geo(SfmHandle* h, DevGeo& g, int K, const int32_t* offsets, const float* px, const float* py,
-                   const std::vector<float4>& ctr4) {
+                   const std::vector<float4>& ctr4, bool may_defer = false) {
     int rc = bind(h);
     if (rc) return rc;
     if (K < 0) return fail(h, SFM_ERR_INVALID, "negative polyline count");
     drop_geo_ahead(h);
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    if (K == 0) { free_geo(g); return SFM_OK; }
+    if (K == 0) { free_geo(g); g.lazy = g.lazy_off = false; return SFM_OK; }
     if (!offsets) return fail(h, SFM_ERR_INVALID, "offsets is NULL");
     if (offsets[0] != 0) return fail(h, SFM_ERR_INVALID, "offsets[0] must be 0");
     for (int k = 0; k < K; ++k)
@@ -554,17 +556,32 @@ static int set_geo(SfmHandle* h, DevGeo& g, int K, const int32_t* offsets, const
     float2* sp = reinterpret_cast<float2*>(g.stage + b_pts);
     for (int p = 0; p < P; ++p) sp[p] = make_float2(px[p], py[p]);
     memcpy(g.stage + b_off, offsets, sizeof(int) * ((size_t)K + 1));
-    if (bytes <= ((size_t)64 << 10)) {
-        // a handful of polylines (the vehicles the simulator reports every tick): one launch reads the pinned block over the bus
-        HIP_TRY(h, launch_unpack_geo(g.stage, g.ctr, K, g.pts, P, g.off, !off_same, h->stream));
+    const bool off_due = !off_same || g.lazy_off;         // (a deferred block that was never spread may have carried new offsets)
+    g.lazy = g.lazy_off = false;
+    if (bytes <= ((size_t)64 << 10) && may_defer) {
+        // the vehicles the simulator reports every tick, in front of a state upload (sfm_step_packed): the block stays staged and the
+        // upload's unpack launch spreads it; anything else that reads the arrays first calls flush_lazy_geo
+        g.lazy = true; g.lazy_off = off_due;
+    } else if (bytes <= ((size_t)64 << 10)) {
+        // a handful of polylines: one launch reads the pinned block over the bus
+        HIP_TRY(h, launch_unpack_geo(g.stage, g.ctr, K, g.pts, P, g.off, off_due, h->stream));
     } else {
         HIP_TRY(h, hipMemcpyAsync(g.ctr, g.stage + b_ctr, sizeof(float4) * (size_t)K, hipMemcpyHostToDevice, h->stream));
         if (P > 0) HIP_TRY(h, hipMemcpyAsync(g.pts, g.stage + b_pts, sizeof(float2) * (size_t)P, hipMemcpyHostToDevice, h->stream));
-        if (!off_same) HIP_TRY(h, hipMemcpyAsync(g.off, g.stage + b_off, sizeof(int) * ((size_t)K + 1), hipMemcpyHostToDevice, h->stream));
+        if (off_due) HIP_TRY(h, hipMemcpyAsync(g.off, g.stage + b_off, sizeof(int) * ((size_t)K + 1), hipMemcpyHostToDevice, h->stream));
     }
     if (!off_same) g.off_host.assign(offsets, offsets + K + 1);
     g.K = K;
     g.P = P;
+    return SFM_OK;
+}
+
+// vehicles staged by sfm_set_dynamic_obstacles_packed and not yet taken along by a state upload: spread them now
+static int flush_lazy_geo(SfmHandle* h) {
+    DevGeo& g = h->dynamics;
+    if (!g.lazy) return SFM_OK;
+    HIP_TRY(h, launch_unpack_geo(g.stage, g.ctr, g.K, g.pts, g.P, g.off, g.lazy_off, h->stream));
+    g.lazy = g.lazy_off = false;
     return SFM_OK;
 }
 
@@ -655,7 +672,7 @@ int sfm_set_dynamic_obstacles_packed(SfmHandle* h, int M, const int32_t* offsets
     std::vector<float4> c4((size_t)(M > 0 ? M : 0));
     for (int k = 0; k < M; ++k) c4[k] = make_float4(cv[4 * k], cv[4 * k + 1], cv[4 * k + 2], cv[4 * k + 3]);
     h->dyn_boxes = false;
-    return set_geo(h, h->dynamics, M, offsets, px, py, c4);
+    return set_geo(h, h->dynamics, M, offsets, px, py, c4, true);
 }
 
 int sfm_set_dynamic_boxes(SfmHandle* h, int M, const int32_t* offsets, const float* ux, const float* uy,
@@ -684,6 +701,8 @@ int sfm_set_dynamic_boxes(SfmHandle* h, int M, const int32_t* offsets, const flo
 
 int sfm_download_dynamic_obstacles(SfmHandle* h, float* cx, float* cy, float* px, float* py) {
     int rc = bind(h);
+    if (rc) return rc;
+    rc = flush_lazy_geo(h);
     if (rc) return rc;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     const int M = h->dynamics.K, P = h->dynamics.P;
@@ -834,13 +853,16 @@ int sfm_upload_state(SfmHandle* h, int N, const float* x, const float* y, const 
     if (b_end <= ((size_t)256 << 10)) {
         // a host-in-the-loop crowd (round 4): the unpack kernel reads the pinned block over the bus by itself -- one launch instead of
         // a copy and a launch in front of every tick (the block is not overwritten before the next upload's stream synchronisation)
+        DevGeo& g = h->dynamics;
         HIP_TRY(h, launch_unpack_rows(h->up_stage, b_own, b_zv, b_rr, b_cm, n_pad, h->pk[0], h->pk[1], h->own, h->zv[0], h->zv[1],
-                                      h->radius, h->crossing, h->draws, h->stream));
+                                      h->radius, h->crossing, h->draws, g.lazy ? g.stage : nullptr, g.ctr, g.K, g.pts, g.P, g.off,
+                                      g.lazy_off, h->stream));
+        g.lazy = g.lazy_off = false;
     } else {
         HIP_TRY(h, dev_reserve(h->up_block, h->up_block_cap, b_end));
         HIP_TRY(h, hipMemcpyAsync(h->up_block, h->up_stage, b_end, hipMemcpyHostToDevice, h->stream));
         HIP_TRY(h, launch_unpack_rows(h->up_block, b_own, b_zv, b_rr, b_cm, n_pad, h->pk[0], h->pk[1], h->own, h->zv[0], h->zv[1],
-                                      h->radius, h->crossing, h->draws, h->stream));
+                                      h->radius, h->crossing, h->draws, nullptr, nullptr, 0, nullptr, 0, nullptr, false, h->stream));
     }
     if (h->reordered) {
         HIP_TRY(h, hipMemcpyAsync(h->ids, h->perm.data(), sizeof(uint32_t) * (size_t)N, hipMemcpyHostToDevice, h->stream));
@@ -1595,6 +1617,8 @@ static int run_ticks(SfmHandle* h, int ticks, uint32_t flags, int phase = PHASE_
     if (phase != PHASE_END) h->timing_valid = false;
     if (h->N == 0 || ticks == 0) return SFM_OK;        // tick() early-out (pedestrian_simulation.py:60-61)
     if (!h->pk[0]) return fail(h, SFM_ERR_STATE, "sfm_upload_state has not been called");
+    rc = flush_lazy_geo(h);
+    if (rc) return rc;
     TickPlan p;
     rc = plan_ticks(h, flags, phase, device_run, carry, p);
     if (rc) return rc;
@@ -1608,6 +1632,8 @@ int sfm_profile_dominant_kernel(SfmHandle* h, int reps, float* avg_us) {
     if (rc) return rc;
     if (reps <= 0 || !avg_us) return fail(h, SFM_ERR_INVALID, "reps <= 0 or avg_us is NULL");
     if (h->N == 0 || !h->pk[0]) return fail(h, SFM_ERR_STATE, "no state uploaded");
+    rc = flush_lazy_geo(h);
+    if (rc) return rc;
     if (h->used_fused) {
         // the last sfm_run took the fused tick: its launches integrate, so they are timed for real on a saved state -- `reps`
         // mid-run launches (integrate + pairs) between the events -- and the state is put back afterwards

@@ -58,12 +58,34 @@ __global__ void sfm_gather_rows_kernel(const uint32_t* __restrict__ src, int N, 
     id_out[s] = id_in[o];
 }
 
+// a small polyline set staged as [ctr | pts | off] words in a pinned host block (launch_unpack_geo below), and where its words go
+struct GeoWords {
+    const uint32_t* block;
+    uint32_t *ctr, *pts, *off;       // off null: the device already holds these offsets
+    int w_ctr, w_pts, w_off;
+};
+
+__device__ __forceinline__ void unpack_geo_words(const GeoWords& g, int first, int step) {
+    const int total = g.w_ctr + g.w_pts + g.w_off;
+    for (int q = first; q < total; q += step) {
+        const uint32_t v = g.block[q];
+        if (q < g.w_ctr) g.ctr[q] = v;
+        else if (q < g.w_ctr + g.w_pts) g.pts[q - g.w_ctr] = v;
+        else if (g.off) g.off[q - g.w_ctr - g.w_pts] = v;
+    }
+}
+
 // sfm_upload_state: the rows arrive as one block [pk | own | zv | radius | crossing]; one thread per row spreads it over the
-// device arrays (both halves of the ping-pong buffers) and zeroes the draw counter.
+// device arrays (both halves of the ping-pong buffers) and zeroes the draw counter.  A vehicle report staged since the last tick
+// (sfm_set_dynamic_obstacles_packed) rides along in one more workgroup: a host-in-the-loop tick is launch-bound, and this was one.
 __global__ void sfm_unpack_rows_kernel(const char* __restrict__ block, size_t b_own, size_t b_zv, size_t b_rr, size_t b_cm,
                                        int n_pad, float4* __restrict__ pk0, float4* __restrict__ pk1, float4* __restrict__ own,
                                        float2* __restrict__ zv0, float2* __restrict__ zv1, float* __restrict__ radius,
-                                       uint8_t* __restrict__ crossing, uint32_t* __restrict__ draws) {
+                                       uint8_t* __restrict__ crossing, uint32_t* __restrict__ draws, int row_blocks, const GeoWords geo) {
+    if ((int)blockIdx.x >= row_blocks) {
+        unpack_geo_words(geo, (int)threadIdx.x, (int)blockDim.x);
+        return;
+    }
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_pad) return;
     const float4 p = reinterpret_cast<const float4*>(block)[s];
@@ -76,34 +98,33 @@ __global__ void sfm_unpack_rows_kernel(const char* __restrict__ block, size_t b_
     draws[s] = 0u;
 }
 
+static GeoWords geo_words(const char* block, float4* ctr, int K, float2* pts, int P, int* off, bool with_off) {
+    return GeoWords{reinterpret_cast<const uint32_t*>(block), reinterpret_cast<uint32_t*>(ctr), reinterpret_cast<uint32_t*>(pts),
+                    with_off ? reinterpret_cast<uint32_t*>(off) : nullptr, 4 * K, 2 * P, K + 1};
+}
+
+// geo_block null: rows only
 hipError_t launch_unpack_rows(const char* block, size_t b_own, size_t b_zv, size_t b_rr, size_t b_cm, int n_pad, float4* pk0,
                               float4* pk1, float4* own, float2* zv0, float2* zv1, float* radius, uint8_t* crossing, uint32_t* draws,
-                              hipStream_t st) {
-    hipLaunchKernelGGL(sfm_unpack_rows_kernel, dim3((n_pad + 255) / 256), dim3(256), 0, st, block, b_own, b_zv, b_rr, b_cm, n_pad,
-                       pk0, pk1, own, zv0, zv1, radius, crossing, draws);
+                              const char* geo_block, float4* ctr, int K, float2* pts, int P, int* off, bool with_off, hipStream_t st) {
+    const int row_blocks = (n_pad + 255) / 256;
+    const GeoWords g = geo_block ? geo_words(geo_block, ctr, K, pts, P, off, with_off) : GeoWords{nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
+    hipLaunchKernelGGL(sfm_unpack_rows_kernel, dim3(row_blocks + (geo_block ? 1 : 0)), dim3(256), 0, st, block, b_own, b_zv, b_rr, b_cm,
+                       n_pad, pk0, pk1, own, zv0, zv1, radius, crossing, draws, row_blocks, g);
     return hipGetLastError();
 }
 
 // set_geo for a small polyline set that arrives every tick (the simulator's vehicles, obstacles.py:297-329): ONE launch reads the
 // pinned host block [ctr | pts | off] over the bus and spreads it over the three device arrays, instead of three small copies
 // (round 4: ~8 us each in front of every host-in-the-loop tick).  Word copies; a few KiB.
-__global__ void sfm_unpack_geo_kernel(const uint32_t* __restrict__ block, uint32_t* __restrict__ ctr, int w_ctr, uint32_t* __restrict__ pts,
-                                      int w_pts, uint32_t* __restrict__ off, int w_off) {
-    const int total = w_ctr + w_pts + w_off;
-    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < total; q += gridDim.x * blockDim.x) {
-        const uint32_t v = block[q];
-        if (q < w_ctr) ctr[q] = v;
-        else if (q < w_ctr + w_pts) pts[q - w_ctr] = v;
-        else if (off) off[q - w_ctr - w_pts] = v;
-    }
+__global__ void sfm_unpack_geo_kernel(const GeoWords g) {
+    unpack_geo_words(g, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 
 hipError_t launch_unpack_geo(const char* block, float4* ctr, int K, float2* pts, int P, int* off, bool with_off, hipStream_t st) {
-    const int w_ctr = 4 * K, w_pts = 2 * P, w_off = K + 1;
-    const int total = w_ctr + w_pts + w_off;
-    hipLaunchKernelGGL(sfm_unpack_geo_kernel, dim3(std::min(64, (total + 255) / 256)), dim3(256), 0, st,
-                       reinterpret_cast<const uint32_t*>(block), reinterpret_cast<uint32_t*>(ctr), w_ctr, reinterpret_cast<uint32_t*>(pts), w_pts,
-                       with_off ? reinterpret_cast<uint32_t*>(off) : nullptr, w_off);
+    const GeoWords g = geo_words(block, ctr, K, pts, P, off, with_off);
+    const int total = g.w_ctr + g.w_pts + g.w_off;
+    hipLaunchKernelGGL(sfm_unpack_geo_kernel, dim3(std::min(64, (total + 255) / 256)), dim3(256), 0, st, g);
     return hipGetLastError();
 }
 

@@ -173,7 +173,9 @@ class SfmEngine:
 
     def set_dynamic_vehicles(self, positions, rings, velocities):
         """The simulator's per-tick vehicle report (obstacles.py:297-329: centres, ring point arrays, velocities) through
-        sfm_set_dynamic_obstacles_packed: one concatenate into a kept fp32 buffer, two array writes, one call with kept addresses."""
+        sfm_set_dynamic_obstacles_packed: one concatenate into a kept fp32 buffer, two array writes, one call with kept addresses.
+        The library keeps a small report staged and lets the next state upload's launch spread it over the device arrays (or the
+        next call that reads them, whichever comes first)."""
         M = len(rings)
         if M == 0:
             return self.set_dynamic_obstacles(None)
@@ -184,6 +186,7 @@ class SfmEngine:
             off[1:] = np.cumsum(lens)
             pts, cv = np.empty((max(int(off[-1]), 1), 2), np.float32), np.zeros((M, 4), np.float32)
             c = self._veh_bufs = (lens, off, pts, cv, off.ctypes.data, pts.ctypes.data, cv.ctypes.data)
+            self._dyn_shape = (M, int(off[-1]), off)
         _, off, pts, cv, p_off, p_pts, p_cv = c
         if off[-1]:
             np.concatenate(rings, axis=0, out=pts[:off[-1]], casting="same_kind")

@@ -1380,3 +1380,76 @@ def test_half_a_million_pedestrians_on_one_gpu():
             P.check_velocity(v[r[0]:r[1]], v_new, expo, 0.05)
     finally:
         eng.close()
+
+
+def test_a_staged_vehicle_report_reaches_every_reader():
+    """sfm_set_dynamic_obstacles_packed keeps a small report staged so that the next state upload's launch can take it along
+    (run_simulation.py:95-114: vehicles, then the tick, every step).  Whatever reads the device arrays first -- a tick without an
+    upload, the download, sfm_step_packed -- must see the report, also when two reports with different ring sizes follow one
+    another with nothing in between.  Reference for each: an engine that was given the same vehicles through
+    sfm_set_dynamic_obstacles (spread at once); bit-identical."""
+    n = 96
+    sc = scenarios.make_scenario(n, 4242, n_dynamic=3)
+    cfg = default_sfm_config(("acceleration_force", "pedestrian_force", "dynamic_obstacle_force"))
+    rng = np.random.default_rng(7)
+
+    def report(points_per_ring, shift):
+        pos, rings = [], []
+        for k, (c, r) in enumerate(sc.dynamic_obstacles):
+            centre = np.asarray(c, dtype=np.float64)[:2] + shift
+            ang = np.linspace(0.0, 2.0 * np.pi, points_per_ring + k, endpoint=False)
+            rings.append(np.float32(centre + np.stack([2.2 * np.cos(ang), 1.0 * np.sin(ang)], axis=1)).astype(np.float64))
+            pos.append(np.float32(centre).astype(np.float64))
+        vel = np.float32(rng.uniform(-3.0, 3.0, size=(len(pos), 2))).astype(np.float64)
+        return np.array(pos), rings, vel
+
+    lazy, eager = SfmEngine(cfg, 0.05), SfmEngine(cfg, 0.05)
+    try:
+        def upload(e):
+            e.upload_state(sc.loc, sc.vel, sc.waypoint, sc.target_speed, sc.radius, None)
+
+        def give(rep, both_ways=True):
+            pos, rings, vel = rep
+            lazy.set_dynamic_vehicles(pos, rings, vel)
+            if both_ways:
+                eager.set_dynamic_obstacles(list(zip(pos, rings)), vel)
+
+        def same_velocities(what):
+            a, b = lazy.velocities(), eager.velocities()
+            assert np.array_equal(a, b), what
+            return a
+
+        # (1) report, then a tick with no upload in between
+        upload(lazy); upload(eager)
+        give(report(6, 0.0))
+        lazy.tick(); eager.tick()
+        v1 = same_velocities("tick right after the report")
+        # (2) the download sees the staged report
+        rep = report(6, 0.5)
+        give(rep)
+        for (c_d, r_d), c_h, r_h in zip(lazy.dynamic_obstacles(), rep[0], rep[1]):
+            assert np.array_equal(c_d, c_h) and np.array_equal(r_d, r_h)
+        # (3) two reports in a row, ring sizes changed, the first never spread; then upload + tick
+        give(report(9, 1.0), both_ways=False)
+        give(report(7, -1.5))
+        upload(lazy); upload(eager)
+        lazy.tick(); eager.tick()
+        v3 = same_velocities("two reports, then upload and tick")
+        assert not np.array_equal(v1, v3)
+        # (4) the one-call tick
+        give(report(7, 2.0))
+        rows = np.zeros((n, 9), np.float32)
+        rows[:, 0:2], rows[:, 2:4], rows[:, 4:6] = sc.loc[:, :2], sc.vel[:, :2], sc.waypoint[:, :2]
+        rows[:, 6], rows[:, 7] = sc.target_speed, sc.radius
+        v_out = np.zeros((n, 3), np.float32)
+        lazy.step_packed(rows, None, v_out)
+        upload(eager); eager.tick()
+        assert np.array_equal(v_out.astype(np.float64)[:, :2], eager.velocities()[:, :2]), "sfm_step_packed"
+        # (5) no vehicles at all after a staged report
+        give(report(7, 0.0), both_ways=False)
+        lazy.set_dynamic_vehicles(np.zeros((0, 2)), [], None); eager.set_dynamic_obstacles(None)
+        upload(lazy); upload(eager)
+        lazy.tick(); eager.tick()
+        same_velocities("report withdrawn")
+    finally:
+        lazy.close(); eager.close()
