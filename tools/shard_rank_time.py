@@ -13,6 +13,8 @@ G = 8 if name == "c5" else 4
 sc, forces = scenarios.baseline_scenario(name)
 if os.environ.get("PROBE_FORCES") == "ped":     # the same crowd without border / obstacle forces
     forces = ("acceleration_force", "pedestrian_force")
+elif os.environ.get("PROBE_FORCES"):            # ... or with one of them: border_force / static_obstacle_force / dynamic_obstacle_force
+    forces = ("acceleration_force", "pedestrian_force") + tuple(os.environ["PROBE_FORCES"].split(","))
 eng = HipShardEngine(default_sfm_config(forces), 0.05)
 eng.set_partition(*block_layout(G))
 n, n_pad = eng.load(sc)
@@ -21,6 +23,9 @@ e = eng.engine
 e.tick()
 e.set_shard(b[r], b[r + 1])
 e.set_timing(False)
+INTEGRATE = os.environ.get("PROBE_INTEGRATE") == "1"     # the rank's own rows walk on (the other ranks' stay: nothing exchanges here)
+if os.environ.get("PROBE_WHOLE") == "1":                  # no shard: the whole crowd's tick, timed the same way
+    e.set_shard(0, n)
 out = []
 for mode in ("plain", "split"):
     def go(k):
@@ -28,7 +33,7 @@ for mode in ("plain", "split"):
             if mode == "split":
                 eng.begin(); eng.end()
             else:
-                e.tick()
+                e.tick(integrate=INTEGRATE)
     go(5); torch.cuda.synchronize()
     t0 = time.perf_counter(); go(200); torch.cuda.synchronize()
     out.append(f"{mode} {(time.perf_counter() - t0) / 200 * 1e6:7.1f} us")
