@@ -92,7 +92,10 @@ int sfm_set_static_obstacles(SfmHandle* h, int M, const int32_t* offsets, const 
 int sfm_set_dynamic_obstacles(SfmHandle* h, int M, const int32_t* offsets, const float* px, const float* py,
                               const float* cx, const float* cy, const float* vx, const float* vy);
 /* The same from packed arrays (ABI 4): pts [P][2] {x, y}, cv [M][4] {cx, cy, vx, vy}; replaces the same two reference calls
- * (forces.py:285-291) for a caller that is handed the vehicles every tick (run_simulation.py:95, obstacles.py:297-329). */
+ * (forces.py:285-291) for a caller that is handed the vehicles every tick (run_simulation.py:95, obstacles.py:297-329).
+ * The arrays are copied before the call returns.  A small report (<= 64 KiB) is only STAGED: the next sfm_upload_state /
+ * sfm_step_packed spreads it over the device arrays in its own launch, and any other call that reads them (a tick without an upload,
+ * sfm_download_dynamic_obstacles, ...) does so first -- no caller-visible difference, one launch less per host-in-the-loop tick. */
 int sfm_set_dynamic_obstacles_packed(SfmHandle* h, int M, const int32_t* offsets, const float* pts, const float* cv);
 
 /* Device-side form of get_dynamic_obstacles (obstacles.py:297-329) for CARLA-free runs:
