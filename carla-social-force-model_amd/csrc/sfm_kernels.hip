@@ -384,6 +384,46 @@ __device__ __forceinline__ bool moussaid_spatial(const IxConst& c, float dx, flo
     return true;
 }
 
+// Two pairs per lane for a 3-D crowd (round 4, late; the fused tick's 8-wave form -- all forces at N = 4096: 24.0 -> 22.5 us): moussaid_spatial's
+// operations on register pairs {pair A, pair B}, the same operations on the same operands per pair.
+__device__ __forceinline__ void moussaid_spatial_x2(const IxConst& c, float pjx, float pjy, float pjz, float ujx, float ujy, float ujz,
+                                                    v2f X, v2f Y, v2f Z, v2f U, v2f V, v2f W, v2f& cx, v2f& cy, v2f& cz) {
+    const v2f dx = bcast(pjx) - X, dy = bcast(pjy) - Y, dz = bcast(pjz) - Z;          // other - self, pairs A and B
+    const v2f d2 = fma2(dx, dx, fma2(dy, dy, dz * dz));
+    const v2f rinv = rsq2(d2);
+    const v2f d = d2 * rinv;
+    const v2f Dx = fma2(dx, rinv, U - bcast(ujx)), Dy = fma2(dy, rinv, V - bcast(ujy)), Dz = fma2(dz, rinv, W - bcast(ujz));
+    const v2f D2 = fma2(Dx, Dx, fma2(Dy, Dy, fma2(Dz, Dz, bcast(TINY))));
+    const v2f rD = rsq2(D2);
+    const v2f aL = d * (rD * bcast(c.c1));
+    const v2f Dn = D2 * rD;                                            // |D|
+    const v2f tx = Dx * rD, ty = Dy * rD, tz = Dz * rD;
+    const v2f S = fma2(tx, dy, -(ty * dx)), C = fma2(tx, dx, ty * dy); // the xy projections' sin / cos, scaled by |t_xy| |d_xy|
+    const v2f h2 = fma2(S, S, C * C);
+    const v2f hm = h2 * rsq2(h2);
+    // half_angle_theta with m = h, both pairs (forces.py:94,101)
+    const v2f sc = copysign2(bcast(1.0f), C);
+    const v2f r = S * rcp2(fma2(sc, hm, C));
+    const v2f z = r * r;
+    v2f p = bcast(-0.0095607885413262813f);
+    p = fma2(p, z, bcast(0.049113825228842972f));
+    p = fma2(p, z, bcast(-0.11980885478692463f));
+    p = fma2(p, z, bcast(0.1988547939908939f));
+    p = fma2(p, z, bcast(-0.28058826128196529f));
+    p = fma2(p, z, bcast(0.39942748114880167f));
+    p = fma2(p, z, bcast(-0.66664186893326649f));
+    p = fma2(p, z, bcast(1.9999998228145017f));
+    const v2f h = copysign2(bcast(1.57079632679489662f), S);
+    const v2f theta = fma2(p, r, fma2(bcast(-c.eg), Dn, fma2(-sc, h, h)));
+    const v2f q = Dn * theta;
+    const v2f q2 = q * q;
+    const v2f e1 = ex22(fma2(q2, bcast(c.k1), aL)), e2 = ex22(fma2(q2, bcast(c.k2), aL));
+    const v2f g = copysign2(e2, theta);
+    cx = fma2(e1, tx, -(g * ty));
+    cy = fma2(e1, ty, g * tx);
+    cz = e1 * tz;
+}
+
 // The 3-D body with its x / y pairs on packed fp32 instructions (round 4; the z components stay scalar): the drop-in CARLA path is a
 // 3-D crowd (pedestrian_state.py:17-19 -- walkers never have exactly equal z), so this is the step real callers run.  Same operations
 // on the same operands as moussaid_spatial, hence the same bits.  d2 comes out of here (3-D squared distance), reach2 as in the planar form.
@@ -2285,22 +2325,29 @@ template <bool RAD, int NW, bool Z3>
 struct FusedShared {                             // LDS of one pair-role workgroup
     float4 st[2 * GROUP];                        // the workgroup's pedestrians in the state the pairs are evaluated on: GX then GY
     float rad[2 * GROUP];
-    float2 q[NW / 2][2 * GROUP];                 // partial column sums
+    float2 q[Z3 ? 1 : NW / 2][2 * GROUP];        // partial column sums (3-D crowds: q / qz lie over fi / fj / fiz / fjz -- the prologue is done with
+                                                 // them two barriers before the first sum of a wave is written -- which pays for the second chain's
+                                                 // sums below: the 8-wave 3-D form stays at three workgroups per CU)
     float2 part[2 * GROUP];                      // exact rows
     int badrow[2 * GROUP];
     int any;
     float2 fi[NW][WAVE];
     float2 fj[NW][WAVE];
-    float2 fi2[(SFM_X2 && !RAD && !Z3) ? NW : 1][WAVE];   // two pairs per lane: the sums of a wave's second travelling chain
+    float fiz[Z3 ? NW : 1][WAVE];                // (3-D: z components; these four arrays are one block of (NW / 2) * 2 * GROUP * 12 bytes = q + qz)
+    float fjz[Z3 ? NW : 1][WAVE];
+    static constexpr bool X2 = SFM_X2 && !RAD && (!Z3 || NW == 8);   // two pairs per lane (3-D: the 8-wave form only -- the 16-wave one has 64 VGPRs and spills with it)
+    float2 fi2[X2 ? NW : 1][WAVE];               // ... the sums of a wave's second travelling chain
+    float fi2z[(X2 && Z3) ? NW : 1][WAVE];
     float4 trav[4][2 * WAVE];                    // the four tiles as travelling operands, each twice back to back (two pairs per lane: as four
                                                  // planes x, y, lambda vx, lambda vy of [4][2 * WAVE] floats -- a lane reads its two pedestrians' x as one ds_read2_b32)
     float radt[RAD ? 4 : 1][2 * WAVE];
     float2 stz[Z3 ? 2 * GROUP : 1];              // 3-D crowds: {z, vz} of the same pedestrians ...
     float2 travz[Z3 ? 4 : 1][2 * WAVE];          // ... {z, lambda vz} as travelling operands
-    float qz[Z3 ? NW / 2 : 1][2 * GROUP];        // ... and the z components of the sums
     float partz[Z3 ? 2 * GROUP : 1];
-    float fiz[Z3 ? NW : 1][WAVE];
-    float fjz[Z3 ? NW : 1][WAVE];
+    __device__ __forceinline__ float2 (*qv())[2 * GROUP] { return Z3 ? reinterpret_cast<float2 (*)[2 * GROUP]>(&fi[0][0]) : q; }
+    __device__ __forceinline__ float (*qzv())[2 * GROUP] {       // 3-D only: behind the (NW / 2) x 2 GROUP float2 of q
+        return reinterpret_cast<float (*)[2 * GROUP]>(reinterpret_cast<char*>(&fi[0][0]) + sizeof(float2) * (NW / 2) * 2 * GROUP);
+    }
 };
 
 #ifdef SFM_EXPERIMENTS
@@ -2319,11 +2366,15 @@ __global__ __launch_bounds__(NW * WAVE, (NW == 8 && Z3) ? 6 : 8) void sfm_fused_
     constexpr int PARTS = NW / 2;                // the slab rows are split over this many 128-thread parts
     constexpr int SPW = 4 * WAVE / NW;           // systolic steps per wave
     constexpr int D = NW / 8;                    // waves per diagonal tile
-    constexpr bool X2 = SFM_X2 && !RAD && !Z3;   // two pairs per lane (moussaid_planar_x2)
+    constexpr bool X2 = FusedShared<RAD, NW, Z3>::X2;   // two pairs per lane (moussaid_planar_x2 / moussaid_spatial_x2)
     using Sh = FusedShared<RAD, NW, Z3>;
     constexpr size_t LDS = (GEO && sizeof(GeoShared<NW>) > sizeof(Sh)) ? sizeof(GeoShared<NW>) : sizeof(Sh);
     __shared__ __attribute__((aligned(16))) char smem[LDS];
     Sh& sh = *reinterpret_cast<Sh*>(smem);
+    static_assert(!Z3 || (offsetof(Sh, fjz) + sizeof(sh.fjz) - offsetof(Sh, fi) == (sizeof(float2) + sizeof(float)) * (NW / 2) * 2 * GROUP &&
+                          offsetof(Sh, fj) == offsetof(Sh, fi) + sizeof(sh.fi) && offsetof(Sh, fiz) == offsetof(Sh, fj) + sizeof(sh.fj) &&
+                          offsetof(Sh, fjz) == offsetof(Sh, fiz) + sizeof(sh.fiz)),
+                  "3-D: q / qz are laid over fi | fj | fiz | fjz, which must be one block of exactly that size");
     FUSED_STAMP(0);
     const int tid = threadIdx.x;
     const int lane = tid & (WAVE - 1);
@@ -2480,9 +2531,9 @@ __global__ __launch_bounds__(NW * WAVE, (NW == 8 && Z3) ? 6 : 8) void sfm_fused_
                 }
             }
         }
-        sh.q[part][2 * pp] = make_float2(acc4.x, acc4.y);
-        sh.q[part][2 * pp + 1] = make_float2(acc4.z, acc4.w);
-        if (Z3) { sh.qz[Z3 ? part : 0][2 * pp] = accz.x; sh.qz[Z3 ? part : 0][2 * pp + 1] = accz.y; }
+        sh.qv()[part][2 * pp] = make_float2(acc4.x, acc4.y);
+        sh.qv()[part][2 * pp + 1] = make_float2(acc4.z, acc4.w);
+        if (Z3) { sh.qzv()[part][2 * pp] = accz.x; sh.qzv()[part][2 * pp + 1] = accz.y; }
     }
     FUSED_STAMP(1);
     __syncthreads();
@@ -2504,8 +2555,14 @@ __global__ __launch_bounds__(NW * WAVE, (NW == 8 && Z3) ? 6 : 8) void sfm_fused_
         if (Z3) {
             sh.stz[Z3 ? p : 0] = nsz;
             const float2 tz = make_float2(nsz.x, a.ped.lam * nsz.y);
+            if (X2) {
+                float* plz = reinterpret_cast<float*>(sh.travz) + (p >> 6) * 2 * WAVE + (p & (WAVE - 1));   // planes z | lambda vz of [4][2 * WAVE] floats
+                plz[0] = tz.x; plz[WAVE] = tz.x;
+                plz[8 * WAVE] = tz.y; plz[9 * WAVE] = tz.y;
+            } else {
             sh.travz[Z3 ? (p >> 6) : 0][p & (WAVE - 1)] = tz;
             sh.travz[Z3 ? (p >> 6) : 0][(p & (WAVE - 1)) + WAVE] = tz;
+            }
         }
     };
     auto finish = [&](const float2 g, const float gz) {
@@ -2555,10 +2612,10 @@ __global__ __launch_bounds__(NW * WAVE, (NW == 8 && Z3) ? 6 : 8) void sfm_fused_
     bool bad = false;
     if (lower && present) {
         if (integrate && live) {
-            float2 g = sh.q[0][p];
-            float gz = Z3 ? sh.qz[0][p] : 0.f;
+            float2 g = sh.qv()[0][p];
+            float gz = Z3 ? sh.qzv()[0][p] : 0.f;
 #pragma unroll
-            for (int k = 1; k < PARTS; ++k) { const float2 q = sh.q[k][p]; g.x += q.x; g.y += q.y; if (Z3) gz += sh.qz[Z3 ? k : 0][p]; }
+            for (int k = 1; k < PARTS; ++k) { const float2 q = sh.qv()[k][p]; g.x += q.x; g.y += q.y; if (Z3) gz += sh.qzv()[k][p]; }
             bad = a.en_ped && (!(fabsf(g.x) < __builtin_inff()) || !(fabsf(g.y) < __builtin_inff()) || (Z3 && !(fabsf(gz) < __builtin_inff())));
             if (bad) sh.any = 1; else finish(g, gz);
         } else {
@@ -2653,7 +2710,7 @@ __global__ __launch_bounds__(NW * WAVE, (NW == 8 && Z3) ? 6 : 8) void sfm_fused_
     }
     float fxi = 0.f, fyi = 0.f, fxj = 0.f, fyj = 0.f, fzi = 0.f, fzj = 0.f;
     int i_end_loc = lane;
-    float fxb = 0.f, fyb = 0.f;                   // X2: the sums of the second travelling chain, and where they end up
+    float fxb = 0.f, fyb = 0.f, fzb = 0.f;        // X2: the sums of the second travelling chain, and where they end up
     int i_end_b = lane;
     if (X2 && work) {
         // Two pairs per lane: the wave's SPW steps are SPW / 2 double steps; chain A meets sigma0 .. sigma0 + SPW/2 - 1, chain B the same
@@ -2663,31 +2720,39 @@ __global__ __launch_bounds__(NW * WAVE, (NW == 8 && Z3) ? 6 : 8) void sfm_fused_
         const IxConst& c = a.ped;
         const float4 pj = sh.st[ib + lane];
         const float ujx = c.lam * pj.z, ujy = c.lam * pj.w;
+        float zj = 0.f, ujz = 0.f;
+        if (Z3) { const float2 qz = sh.stz[Z3 ? ib + lane : 0]; zj = qz.x; ujz = c.lam * qz.y; }
         constexpr int HALF = SPW / 2;
         const int s0 = diag ? 1 + ((sig0 - 1) >> 1) : sig0 >> 1;      // (sig0 was laid out for SPW steps per wave: 1 + j SPW / j SPW)
         const float* pl = reinterpret_cast<const float*>(sh.trav) + (ia >> 6) * 2 * WAVE + lane + s0;
-        v2f fjx = bcast(0.f), fjy = bcast(0.f);
+        const float* plz = reinterpret_cast<const float*>(sh.travz) + (Z3 ? (ia >> 6) * 2 * WAVE + lane + s0 : 0);
+        v2f fjx = bcast(0.f), fjy = bcast(0.f), fjzv = bcast(0.f);
         auto chain = [&](auto xb_tag) __attribute__((always_inline)) {
             constexpr int XB = decltype(xb_tag)::value;
             const bool tail_one_sided = diag && (s0 + XB + HALF - 1 == 32);       // sigma = 32 on a diagonal tile: one-sided (uniform)
             v2f X, Y, U, V;
             X.x = pl[0]; X.y = pl[XB]; Y.x = pl[8 * WAVE]; Y.y = pl[8 * WAVE + XB];
             U.x = pl[16 * WAVE]; U.y = pl[16 * WAVE + XB]; V.x = pl[24 * WAVE]; V.y = pl[24 * WAVE + XB];
+            v2f Zp = bcast(0.f), Wp = bcast(0.f);
+            if (Z3) { Zp.x = plz[0]; Zp.y = plz[XB]; Wp.x = plz[8 * WAVE]; Wp.y = plz[8 * WAVE + XB]; }
 #pragma unroll
             for (int s_ = 0; s_ < HALF; ++s_) {
-                v2f Xn = X, Yn = Y, Un = U, Vn = V;
+                v2f Xn = X, Yn = Y, Un = U, Vn = V, Zn = Zp, Wn = Wp;
                 if (s_ + 1 < HALF) {                                  // the next double step's operands are in flight during this one
                     Xn.x = pl[s_ + 1]; Xn.y = pl[s_ + 1 + XB]; Yn.x = pl[8 * WAVE + s_ + 1]; Yn.y = pl[8 * WAVE + s_ + 1 + XB];
                     Un.x = pl[16 * WAVE + s_ + 1]; Un.y = pl[16 * WAVE + s_ + 1 + XB]; Vn.x = pl[24 * WAVE + s_ + 1]; Vn.y = pl[24 * WAVE + s_ + 1 + XB];
+                    if (Z3) { Zn.x = plz[s_ + 1]; Zn.y = plz[s_ + 1 + XB]; Wn.x = plz[8 * WAVE + s_ + 1]; Wn.y = plz[8 * WAVE + s_ + 1 + XB]; }
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                v2f cx, cy;
-                moussaid_planar_x2(c, pj.x, pj.y, ujx, ujy, X, Y, U, V, cx, cy);
+                v2f cx, cy, cz = bcast(0.f);
+                if (Z3) moussaid_spatial_x2(c, pj.x, pj.y, zj, ujx, ujy, ujz, X, Y, Zp, U, V, Wp, cx, cy, cz);
+                else moussaid_planar_x2(c, pj.x, pj.y, ujx, ujy, X, Y, U, V, cx, cy);
                 fxi = rot_in(fxi) + cx.x; fyi = rot_in(fyi) + cy.x;
                 fxb = rot_in(fxb) + cx.y; fyb = rot_in(fyb) + cy.y;
-                if (s_ + 1 == HALF && tail_one_sided) { fjx.x -= cx.x; fjy.x -= cy.x; }      // (chain B's last pair: the travelling side only)
-                else { fjx -= cx; fjy -= cy; }
-                X = Xn; Y = Yn; U = Un; V = Vn;
+                if (Z3) { fzi = rot_in(fzi) + cz.x; fzb = rot_in(fzb) + cz.y; }
+                if (s_ + 1 == HALF && tail_one_sided) { fjx.x -= cx.x; fjy.x -= cy.x; if (Z3) fjzv.x -= cz.x; }      // (chain B's last pair: the travelling side only)
+                else { fjx -= cx; fjy -= cy; if (Z3) fjzv -= cz; }
+                X = Xn; Y = Yn; U = Un; V = Vn; Zp = Zn; Wp = Wn;
                 __builtin_amdgcn_sched_barrier(0);
             }
             i_end_loc = (lane + s0 + HALF - 1) & (WAVE - 1);
@@ -2697,6 +2762,7 @@ __global__ __launch_bounds__(NW * WAVE, (NW == 8 && Z3) ? 6 : 8) void sfm_fused_
         else chain(std::integral_constant<int, 32>{});
         fxj = fjx.x + fjx.y;
         fyj = fjy.x + fjy.y;
+        if (Z3) fzj = fjzv.x + fjzv.y;
     } else
     if (work) {
         const IxConst& c = a.ped;
@@ -2766,6 +2832,7 @@ __global__ __launch_bounds__(NW * WAVE, (NW == 8 && Z3) ? 6 : 8) void sfm_fused_
     FUSED_WAVE_STAMP(0);
     sh.fi[wave][i_end_loc] = make_float2(fxi, fyi);
     if (X2) sh.fi2[X2 ? wave : 0][i_end_b] = make_float2(fxb, fyb);
+    if (X2 && Z3) sh.fi2z[(X2 && Z3) ? wave : 0][i_end_b] = fzb;
     sh.fj[wave][lane] = make_float2(fxj, fyj);
     if (Z3) { sh.fiz[Z3 ? wave : 0][i_end_loc] = fzi; sh.fjz[Z3 ? wave : 0][lane] = fzj; }
     FUSED_STAMP(3);
@@ -2777,7 +2844,9 @@ __global__ __launch_bounds__(NW * WAVE, (NW == 8 && Z3) ? 6 : 8) void sfm_fused_
     auto fi = [&](int w) {
         float2 v = sh.fi[w][l];
         if (X2) { const float2 v2 = sh.fi2[X2 ? w : 0][l]; v.x += v2.x; v.y += v2.y; }       // (both travelling chains of the wave)
-        return make_float3(v.x, v.y, Z3 ? sh.fiz[Z3 ? w : 0][l] : 0.f);
+        float vz_ = Z3 ? sh.fiz[Z3 ? w : 0][l] : 0.f;
+        if (X2 && Z3) vz_ += sh.fi2z[(X2 && Z3) ? w : 0][l];
+        return make_float3(v.x, v.y, vz_);
     };
     auto fj = [&](int w) { const float2 v = sh.fj[w][l]; return make_float3(v.x, v.y, Z3 ? sh.fjz[Z3 ? w : 0][l] : 0.f); };
     float3 r = make_float3(0.f, 0.f, 0.f);
