@@ -314,8 +314,9 @@ __device__ __forceinline__ v2f rcp2(v2f v) { v2f r; r.x = rcp(v.x); r.y = rcp(v.
 __device__ __forceinline__ v2f ex22(v2f v) { v2f r; r.x = ex2(v.x); r.y = ex2(v.y); return r; }
 __device__ __forceinline__ v2f copysign2(v2f m, v2f sg) { v2f r; r.x = copysignf(m.x, sg.x); r.y = copysignf(m.y, sg.y); return r; }
 __device__ __forceinline__ v2f fma2(v2f a_, v2f b_, v2f c_) { return __builtin_elementwise_fma(a_, b_, c_); }
+template <bool RAD = false>
 __device__ __forceinline__ void moussaid_planar_x2(const IxConst& c, float pjx, float pjy, float ujx, float ujy, v2f X, v2f Y, v2f U, v2f V,
-                                                   v2f& cx, v2f& cy) {
+                                                   v2f& cx, v2f& cy, v2f rsum = v2f{0.f, 0.f}) {
     const v2f dx = bcast(pjx) - X, dy = bcast(pjy) - Y;                // other - self, pairs A and B
     const v2f d2 = fma2(dx, dx, dy * dy);
     const v2f rinv = rsq2(d2);
@@ -323,7 +324,7 @@ __device__ __forceinline__ void moussaid_planar_x2(const IxConst& c, float pjx, 
     const v2f Dx = fma2(dx, rinv, U - bcast(ujx)), Dy = fma2(dy, rinv, V - bcast(ujy));     // D = e + lambda (v_i - v_j)
     const v2f D2 = fma2(Dx, Dx, fma2(Dy, Dy, bcast(TINY)));
     const v2f rD = rsq2(D2);
-    const v2f aL = d * (rD * bcast(c.c1));
+    const v2f aL = (RAD ? d - rsum : d) * (rD * bcast(c.c1));      // forces.py:80-81: the radii come off the distance
     const v2f Dn = D2 * rD;                                            // |D|
     const v2f tx = Dx * rD, ty = Dy * rD;
     const v2f S = fma2(tx, dy, -(ty * dx)), C = fma2(tx, dx, ty * dy); // d sin, d cos of angle(e) - angle(t)
@@ -386,8 +387,9 @@ __device__ __forceinline__ bool moussaid_spatial(const IxConst& c, float dx, flo
 
 // Two pairs per lane for a 3-D crowd (round 4, late; the fused tick's 8-wave form -- all forces at N = 4096: 24.0 -> 22.5 us): moussaid_spatial's
 // operations on register pairs {pair A, pair B}, the same operations on the same operands per pair.
+template <bool RAD = false>
 __device__ __forceinline__ void moussaid_spatial_x2(const IxConst& c, float pjx, float pjy, float pjz, float ujx, float ujy, float ujz,
-                                                    v2f X, v2f Y, v2f Z, v2f U, v2f V, v2f W, v2f& cx, v2f& cy, v2f& cz) {
+                                                    v2f X, v2f Y, v2f Z, v2f U, v2f V, v2f W, v2f& cx, v2f& cy, v2f& cz, v2f rsum = v2f{0.f, 0.f}) {
     const v2f dx = bcast(pjx) - X, dy = bcast(pjy) - Y, dz = bcast(pjz) - Z;          // other - self, pairs A and B
     const v2f d2 = fma2(dx, dx, fma2(dy, dy, dz * dz));
     const v2f rinv = rsq2(d2);
@@ -395,7 +397,7 @@ __device__ __forceinline__ void moussaid_spatial_x2(const IxConst& c, float pjx,
     const v2f Dx = fma2(dx, rinv, U - bcast(ujx)), Dy = fma2(dy, rinv, V - bcast(ujy)), Dz = fma2(dz, rinv, W - bcast(ujz));
     const v2f D2 = fma2(Dx, Dx, fma2(Dy, Dy, fma2(Dz, Dz, bcast(TINY))));
     const v2f rD = rsq2(D2);
-    const v2f aL = d * (rD * bcast(c.c1));
+    const v2f aL = (RAD ? d - rsum : d) * (rD * bcast(c.c1));
     const v2f Dn = D2 * rD;                                            // |D|
     const v2f tx = Dx * rD, ty = Dy * rD, tz = Dz * rD;
     const v2f S = fma2(tx, dy, -(ty * dx)), C = fma2(tx, dx, ty * dy); // the xy projections' sin / cos, scaled by |t_xy| |d_xy|
@@ -2335,7 +2337,7 @@ struct FusedShared {                             // LDS of one pair-role workgro
     float2 fj[NW][WAVE];
     float fiz[Z3 ? NW : 1][WAVE];                // (3-D: z components; these four arrays are one block of (NW / 2) * 2 * GROUP * 12 bytes = q + qz)
     float fjz[Z3 ? NW : 1][WAVE];
-    static constexpr bool X2 = SFM_X2 && !RAD && (!Z3 || NW == 8);   // two pairs per lane (3-D: the 8-wave form only -- the 16-wave one has 64 VGPRs and spills with it)
+    static constexpr bool X2 = SFM_X2 && (!Z3 || NW == 8);   // two pairs per lane (3-D: the 8-wave form only -- the 16-wave one has 64 VGPRs and spills with it)
     float2 fi2[X2 ? NW : 1][WAVE];               // ... the sums of a wave's second travelling chain
     float fi2z[(X2 && Z3) ? NW : 1][WAVE];
     float4 trav[4][2 * WAVE];                    // the four tiles as travelling operands, each twice back to back (two pairs per lane: as four
@@ -2722,10 +2724,13 @@ __global__ __launch_bounds__(NW * WAVE, (NW == 8 && Z3) ? 6 : 8) void sfm_fused_
         const float ujx = c.lam * pj.z, ujy = c.lam * pj.w;
         float zj = 0.f, ujz = 0.f;
         if (Z3) { const float2 qz = sh.stz[Z3 ? ib + lane : 0]; zj = qz.x; ujz = c.lam * qz.y; }
+        float rj = 0.f;
+        if (RAD) rj = sh.rad[ib + lane];
         constexpr int HALF = SPW / 2;
         const int s0 = diag ? 1 + ((sig0 - 1) >> 1) : sig0 >> 1;      // (sig0 was laid out for SPW steps per wave: 1 + j SPW / j SPW)
         const float* pl = reinterpret_cast<const float*>(sh.trav) + (ia >> 6) * 2 * WAVE + lane + s0;
         const float* plz = reinterpret_cast<const float*>(sh.travz) + (Z3 ? (ia >> 6) * 2 * WAVE + lane + s0 : 0);
+        const float* plr = &sh.radt[RAD ? (ia >> 6) : 0][RAD ? lane + s0 : 0];
         v2f fjx = bcast(0.f), fjy = bcast(0.f), fjzv = bcast(0.f);
         auto chain = [&](auto xb_tag) __attribute__((always_inline)) {
             constexpr int XB = decltype(xb_tag)::value;
@@ -2733,26 +2738,28 @@ __global__ __launch_bounds__(NW * WAVE, (NW == 8 && Z3) ? 6 : 8) void sfm_fused_
             v2f X, Y, U, V;
             X.x = pl[0]; X.y = pl[XB]; Y.x = pl[8 * WAVE]; Y.y = pl[8 * WAVE + XB];
             U.x = pl[16 * WAVE]; U.y = pl[16 * WAVE + XB]; V.x = pl[24 * WAVE]; V.y = pl[24 * WAVE + XB];
-            v2f Zp = bcast(0.f), Wp = bcast(0.f);
+            v2f Zp = bcast(0.f), Wp = bcast(0.f), Rp = bcast(0.f);
             if (Z3) { Zp.x = plz[0]; Zp.y = plz[XB]; Wp.x = plz[8 * WAVE]; Wp.y = plz[8 * WAVE + XB]; }
+            if (RAD) { Rp.x = plr[0]; Rp.y = plr[XB]; }
 #pragma unroll
             for (int s_ = 0; s_ < HALF; ++s_) {
-                v2f Xn = X, Yn = Y, Un = U, Vn = V, Zn = Zp, Wn = Wp;
+                v2f Xn = X, Yn = Y, Un = U, Vn = V, Zn = Zp, Wn = Wp, Rn = Rp;
                 if (s_ + 1 < HALF) {                                  // the next double step's operands are in flight during this one
                     Xn.x = pl[s_ + 1]; Xn.y = pl[s_ + 1 + XB]; Yn.x = pl[8 * WAVE + s_ + 1]; Yn.y = pl[8 * WAVE + s_ + 1 + XB];
                     Un.x = pl[16 * WAVE + s_ + 1]; Un.y = pl[16 * WAVE + s_ + 1 + XB]; Vn.x = pl[24 * WAVE + s_ + 1]; Vn.y = pl[24 * WAVE + s_ + 1 + XB];
                     if (Z3) { Zn.x = plz[s_ + 1]; Zn.y = plz[s_ + 1 + XB]; Wn.x = plz[8 * WAVE + s_ + 1]; Wn.y = plz[8 * WAVE + s_ + 1 + XB]; }
+                    if (RAD) { Rn.x = plr[s_ + 1]; Rn.y = plr[s_ + 1 + XB]; }
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 v2f cx, cy, cz = bcast(0.f);
-                if (Z3) moussaid_spatial_x2(c, pj.x, pj.y, zj, ujx, ujy, ujz, X, Y, Zp, U, V, Wp, cx, cy, cz);
-                else moussaid_planar_x2(c, pj.x, pj.y, ujx, ujy, X, Y, U, V, cx, cy);
+                if (Z3) moussaid_spatial_x2<RAD>(c, pj.x, pj.y, zj, ujx, ujy, ujz, X, Y, Zp, U, V, Wp, cx, cy, cz, Rp + bcast(rj));
+                else moussaid_planar_x2<RAD>(c, pj.x, pj.y, ujx, ujy, X, Y, U, V, cx, cy, Rp + bcast(rj));
                 fxi = rot_in(fxi) + cx.x; fyi = rot_in(fyi) + cy.x;
                 fxb = rot_in(fxb) + cx.y; fyb = rot_in(fyb) + cy.y;
                 if (Z3) { fzi = rot_in(fzi) + cz.x; fzb = rot_in(fzb) + cz.y; }
                 if (s_ + 1 == HALF && tail_one_sided) { fjx.x -= cx.x; fjy.x -= cy.x; if (Z3) fjzv.x -= cz.x; }      // (chain B's last pair: the travelling side only)
                 else { fjx -= cx; fjy -= cy; if (Z3) fjzv -= cz; }
-                X = Xn; Y = Yn; U = Un; V = Vn; Zp = Zn; Wp = Wn;
+                X = Xn; Y = Yn; U = Un; V = Vn; Zp = Zn; Wp = Wn; Rp = Rn;
                 __builtin_amdgcn_sched_barrier(0);
             }
             i_end_loc = (lane + s0 + HALF - 1) & (WAVE - 1);
