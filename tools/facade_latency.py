@@ -27,7 +27,7 @@ def timed(fn, reps=300, spread=None):
 print("one drop-in tick = sim.update_dynamic_obstacles(...) + sim.tick(t) + sim.get_new_velocities(), all five forces, 4 (2 at N = 20) vehicles whose rings")
 print("are re-uploaded every tick, record_states off; microseconds, MEDIAN of 300 ticks after 20 (reference NumPy tick: ~25 ms at N = 64)")
 for quiet, (n, nb, ns, nd) in enumerate(((64, 40, 16, 4), (20, 8, 4, 2), (64, 40, 16, 4), (512, 40, 16, 4))):      # (the first pass only warms the process up: its numbers are dropped)
-    sc = scenarios.make_scenario(n, 1, nb, ns, nd)
+    sc = scenarios.make_scenario(n, 1, nb, ns, nd, z_spread=float(os.environ.get("Z", "0")))     # Z=0.3: walkers on uneven ground (the 3-D bodies)
     info = [[sc.border_centers[k], float(sc.border_lengths[k])] for k in range(nb)]
     sim = PedestrianSimulation(sc.borders, info, sc.static_obstacles, default_sfm_config(), 0.05, record_states=False)
     for i in range(n):
