@@ -2337,7 +2337,7 @@ struct FusedShared {                             // LDS of one pair-role workgro
     float2 fj[NW][WAVE];
     float fiz[Z3 ? NW : 1][WAVE];                // (3-D: z components; these four arrays are one block of (NW / 2) * 2 * GROUP * 12 bytes = q + qz)
     float fjz[Z3 ? NW : 1][WAVE];
-    static constexpr bool X2 = SFM_X2 && (!Z3 || NW == 8);   // two pairs per lane (3-D: the 8-wave form only -- the 16-wave one has 64 VGPRs and spills with it)
+    static constexpr bool X2 = SFM_X2;           // two pairs per lane: every form of the pair role (round 4, late: also with radii, also 3-D)
     float2 fi2[X2 ? NW : 1][WAVE];               // ... the sums of a wave's second travelling chain
     float fi2z[(X2 && Z3) ? NW : 1][WAVE];
     float4 trav[4][2 * WAVE];                    // the four tiles as travelling operands, each twice back to back (two pairs per lane: as four
@@ -2743,8 +2743,15 @@ __global__ __launch_bounds__(NW * WAVE, (NW == 8 && Z3) ? 6 : 8) void sfm_fused_
             if (RAD) { Rp.x = plr[0]; Rp.y = plr[XB]; }
 #pragma unroll
             for (int s_ = 0; s_ < HALF; ++s_) {
+                constexpr bool PRE = !(Z3 && NW == 16);             // (the 16-wave 3-D form has 64 VGPRs: no operands in flight across a double step)
+                if (!PRE && s_ > 0) {
+                    X.x = pl[s_]; X.y = pl[s_ + XB]; Y.x = pl[8 * WAVE + s_]; Y.y = pl[8 * WAVE + s_ + XB];
+                    U.x = pl[16 * WAVE + s_]; U.y = pl[16 * WAVE + s_ + XB]; V.x = pl[24 * WAVE + s_]; V.y = pl[24 * WAVE + s_ + XB];
+                    if (Z3) { Zp.x = plz[s_]; Zp.y = plz[s_ + XB]; Wp.x = plz[8 * WAVE + s_]; Wp.y = plz[8 * WAVE + s_ + XB]; }
+                    if (RAD) { Rp.x = plr[s_]; Rp.y = plr[s_ + XB]; }
+                }
                 v2f Xn = X, Yn = Y, Un = U, Vn = V, Zn = Zp, Wn = Wp, Rn = Rp;
-                if (s_ + 1 < HALF) {                                  // the next double step's operands are in flight during this one
+                if (PRE && s_ + 1 < HALF) {                                  // the next double step's operands are in flight during this one
                     Xn.x = pl[s_ + 1]; Xn.y = pl[s_ + 1 + XB]; Yn.x = pl[8 * WAVE + s_ + 1]; Yn.y = pl[8 * WAVE + s_ + 1 + XB];
                     Un.x = pl[16 * WAVE + s_ + 1]; Un.y = pl[16 * WAVE + s_ + 1 + XB]; Vn.x = pl[24 * WAVE + s_ + 1]; Vn.y = pl[24 * WAVE + s_ + 1 + XB];
                     if (Z3) { Zn.x = plz[s_ + 1]; Zn.y = plz[s_ + 1 + XB]; Wn.x = plz[8 * WAVE + s_ + 1]; Wn.y = plz[8 * WAVE + s_ + 1 + XB]; }
