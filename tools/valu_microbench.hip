@@ -67,6 +67,20 @@ __global__ void k(float* out, int iters, float seed, unsigned long long* stamps)
             if (OP == 47) { X8(asm volatile("v_add_f32_dpp %0, %0, %1 row_ror:1 row_mask:0xf bank_mask:0xf" : "+v"(a) : "v"(d));) }
             if (OP == 45) { X8(asm volatile("v_mul_f32_e32 %0, 0.5, %0" : "+v"(a));) }
 #undef X8
+        } else if (OP >= 48 && OP <= 55) {  // bitwise forms a copysign can be made of (round 4: is any of them full rate?)
+            const float sc = seed * 3.0f;
+#define X8(stmt) { float& a = a0; stmt } { float& a = a1; stmt } { float& a = a2; stmt } { float& a = a3; stmt } \
+                 { float& a = a4; stmt } { float& a = a5; stmt } { float& a = a6; stmt } { float& a = a7; stmt }
+            if (OP == 48) { X8(asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(a) : "s"(0x80000000), "v"(c));) }
+            if (OP == 49) { X8(asm volatile("v_and_b32_e32 %0, %1, %0" : "+v"(a) : "s"(0xbfffffff));) }
+            if (OP == 50) { X8(asm volatile("v_or_b32_e32 %0, %1, %0" : "+v"(a) : "v"(c));) }
+            if (OP == 51) { X8(asm volatile("v_xor_b32_e32 %0, %1, %0" : "+v"(a) : "v"(c));) }
+            if (OP == 52) { X8(asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(a) : "v"(d), "v"(c));) }
+            if (OP == 53) { X8(asm volatile("v_mul_f32_e64 %0, |%0|, %1" : "+v"(a) : "v"(c));) }
+            if (OP == 54) { X8(asm volatile("v_lshl_or_b32 %0, %0, 0, %1" : "+v"(a) : "v"(c));) }
+            if (OP == 55) { X8(asm volatile("v_mov_b32_e32 %0, %1" : "+v"(a) : "v"(c));) }
+            (void)sc;
+#undef X8
         } else if (OP >= 12 && OP <= 21) {  // single instructions, forced encodings, 8 independent accumulators
             const float sc = seed * 3.0f;   // lands in an SGPR
 #define X8(stmt) { float& a = a0; stmt } { float& a = a1; stmt } { float& a = a2; stmt } { float& a = a3; stmt } \
@@ -126,6 +140,8 @@ int main() {
         run<38>("mul_e64 v,-v", w, 1); run<39>("v_fmamk", w, 1); run<40>("sub_e32 s,v", w, 1); run<41>("add_e32 1.0,v", w, 1);
         run<42>("v_max_i32", w, 1); run<43>("fma v,v,s", w, 1); run<44>("cndmask only", w, 1); run<45>("mul_e32 0.5,v", w, 1);
         run<46>("add_dpp wave_rol", w, 1); run<47>("add_dpp row_ror", w, 1);
+        run<48>("v_and_or s,v", w, 1); run<49>("v_and_b32", w, 1); run<50>("v_or_b32", w, 1); run<51>("v_xor_b32", w, 1);
+        run<52>("v_and_or v,v", w, 1); run<53>("mul |v|,v", w, 1); run<54>("v_lshl_or", w, 1); run<55>("v_mov", w, 1);
     }
     return 0;
 }
