@@ -14,8 +14,8 @@ import numpy as np
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SFM_LIB_PATH") or os.path.join(PKG_DIR, "libsfm_hip.so")   # (the override is for A/B builds of the kernels)
-ABI_VERSION = 4
-SINCE = {"sfm_step_packed": 4, "sfm_set_dynamic_obstacles_packed": 4}      # entry points younger than ABI 3: an OLDER build named by SFM_LIB_PATH (A/B of builds) may lack them
+ABI_VERSION = 5
+SINCE = {"sfm_step_packed": 4, "sfm_set_dynamic_obstacles_packed": 4, "sfm_step_records": 5}      # entry points younger than ABI 3: an OLDER build named by SFM_LIB_PATH (A/B of builds) may lack them
 
 FORCE_NAMES = ("acceleration_force", "pedestrian_force", "border_force",
                "static_obstacle_force", "dynamic_obstacle_force")
@@ -69,6 +69,7 @@ SYMBOLS = {
     "sfm_run_recorded": (C.c_int, [_H, C.c_int, C.c_uint32, C.c_int, _F, C.c_int, C.POINTER(C.c_int)]),
     "sfm_download_velocities": (C.c_int, [_H, _F, _F, _F]),
     "sfm_step_packed": (C.c_int, [_H, C.c_int, _F, _F, C.c_uint32, _F]),
+    "sfm_step_records": (C.c_int, [_H, C.c_int, C.c_void_p, C.c_int64, _I, _U8, C.c_float, C.c_uint32, _F, C.POINTER(C.c_int32)]),
     "sfm_set_dynamic_obstacles_packed": (C.c_int, [_H, C.c_int, _I, _F, _F]),
     "sfm_download_state": (C.c_int, [_H, _F, _F, _F, _F, _F, _F, _F, _F]),
     "sfm_download_forces": (C.c_int, [_H, C.c_int, _F, _F, _F]),

@@ -1822,22 +1822,13 @@ int sfm_download_velocities(SfmHandle* h, float* vx, float* vy, float* vz) {
 // The block is taken apart into the arrays sfm_upload_state consumes (crowds that go through here are host-in-the-loop crowds of a
 // few thousand pedestrians at most: a pass over 36 N bytes), so everything an upload settles -- packing, padding rows, capacities --
 // is settled by the same code; v' comes back through a pinned block.
-int sfm_step_packed(SfmHandle* h, int N, const float* rows, const float* zvz, uint32_t flags, float* v_out) {
-    if (!h) return SFM_ERR_INVALID;
-    if (N < 0 || (N > 0 && (!rows || !v_out))) { int rc = bind(h); return rc ? rc : fail(h, SFM_ERR_INVALID, "N < 0, or rows / v_out is NULL"); }
-    std::vector<float>& c = h->step_cols;
+// sfm_step_packed / sfm_step_records behind their column fill: h->step_cols holds {x, y, vx, vy, wx, wy, ts, rr, z, vz} [N] each and
+// h->step_mask the border-force-off flags; upload, one tick with its last kernel writing v' into pinned host memory, v' out.
+static int step_core(SfmHandle* h, int N, bool z3, uint32_t flags, float* v_out) {
     const size_t n = (size_t)N;
-    c.resize(10 * n + 1);
-    float *x = c.data(), *y = x + n, *vx = y + n, *vy = vx + n, *wx = vy + n, *wy = wx + n, *ts = wy + n, *rr = ts + n, *z = rr + n, *vz = z + n;
-    h->step_mask.resize(n + 1);
-    uint8_t* cm = h->step_mask.data();
-    for (size_t i = 0; i < n; ++i) {
-        const float* r = rows + 9 * i;
-        x[i] = r[0]; y[i] = r[1]; vx[i] = r[2]; vy[i] = r[3]; wx[i] = r[4]; wy[i] = r[5]; ts[i] = r[6]; rr[i] = r[7];
-        cm[i] = r[8] != 0.0f ? 1 : 0;
-        if (zvz) { z[i] = zvz[2 * i]; vz[i] = zvz[2 * i + 1]; }
-    }
-    int rc = sfm_upload_state(h, N, x, y, zvz ? z : nullptr, vx, vy, zvz ? vz : nullptr, wx, wy, ts, rr, cm);
+    float* c = h->step_cols.data();
+    float *x = c, *y = x + n, *vx = y + n, *vy = vx + n, *wx = vy + n, *wy = wx + n, *ts = wy + n, *rr = ts + n, *z = rr + n, *vz = z + n;
+    int rc = sfm_upload_state(h, N, x, y, z3 ? z : nullptr, vx, vy, z3 ? vz : nullptr, wx, wy, ts, rr, h->step_mask.data());
     if (rc || N == 0) return rc;
     // v' of all rows (the upload reset the shard): the tick's last kernel writes the new rows into a pinned host block as well, so
     // after the stream has drained they are simply there -- no device-to-host copy on the way back
@@ -1860,6 +1851,72 @@ int sfm_step_packed(SfmHandle* h, int N, const float* rows, const float* zvz, ui
         v_out[3 * i] = pk[s_].z; v_out[3 * i + 1] = pk[s_].w; v_out[3 * i + 2] = h->z3 ? zv[s_].y : 0.f;
     }
     return SFM_OK;
+}
+
+int sfm_step_packed(SfmHandle* h, int N, const float* rows, const float* zvz, uint32_t flags, float* v_out) {
+    if (!h) return SFM_ERR_INVALID;
+    if (N < 0 || (N > 0 && (!rows || !v_out))) { int rc = bind(h); return rc ? rc : fail(h, SFM_ERR_INVALID, "N < 0, or rows / v_out is NULL"); }
+    std::vector<float>& c = h->step_cols;
+    const size_t n = (size_t)N;
+    c.resize(10 * n + 1);
+    float *x = c.data(), *y = x + n, *vx = y + n, *vy = vx + n, *wx = vy + n, *wy = wx + n, *ts = wy + n, *rr = ts + n, *z = rr + n, *vz = z + n;
+    h->step_mask.resize(n + 1);
+    uint8_t* cm = h->step_mask.data();
+    for (size_t i = 0; i < n; ++i) {
+        const float* r = rows + 9 * i;
+        x[i] = r[0]; y[i] = r[1]; vx[i] = r[2]; vy[i] = r[3]; wx[i] = r[4]; wy[i] = r[5]; ts[i] = r[6]; rr[i] = r[7];
+        cm[i] = r[8] != 0.0f ? 1 : 0;
+        if (zvz) { z[i] = zvz[2 * i]; vz[i] = zvz[2 * i + 1]; }
+    }
+    return step_core(h, N, zvz != nullptr, flags, v_out);
+}
+
+// The same straight from the caller's RECORDS (ABI 5): what PedestrianState keeps per pedestrian is one packed structured-array row
+// (pedestrian_state.py:17-23: name, id, loc[3], vel[3], next_waypoint[3], mode object, radius, target_speed -- 132 bytes, float64 fields
+// at unaligned offsets), and pedestrian_simulation.py:57-83 reads five of its fields every tick.  Gathering them here instead of in six
+// strided NumPy assignments takes 5-10 us off a drop-in tick.
+int sfm_step_records(SfmHandle* h, int N, const void* records, int64_t stride, const int32_t* field_offsets, const uint8_t* border_off,
+                     float planar_tolerance, uint32_t flags, float* v_out, int32_t* was_planar) {
+    if (!h) return SFM_ERR_INVALID;
+    if (N < 0 || (N > 0 && (!records || !field_offsets || !v_out)) || stride < 0) {
+        int rc = bind(h);
+        return rc ? rc : fail(h, SFM_ERR_INVALID, "N < 0, negative stride, or records / field_offsets / v_out is NULL");
+    }
+    std::vector<float>& c = h->step_cols;
+    const size_t n = (size_t)N;
+    c.resize(10 * n + 1);
+    float *x = c.data(), *y = x + n, *vx = y + n, *vy = vx + n, *wx = vy + n, *wy = wx + n, *ts = wy + n, *rr = ts + n, *z = rr + n, *vz = z + n;
+    h->step_mask.resize(n + 1);
+    uint8_t* cm = h->step_mask.data();
+    const char* base = static_cast<const char*>(records);
+    const int o_loc = field_offsets[0], o_vel = field_offsets[1], o_wp = field_offsets[2], o_rad = field_offsets[3], o_ts = field_offsets[4];
+    double z0 = 0.0, z_lo = 0.0, z_hi = 0.0, vz_max = 0.0;
+    bool flat = true;
+    for (size_t i = 0; i < n; ++i) {
+        const char* r = base + (size_t)stride * i;
+        double l[3], v[3], w[2], rad, t;                   // (memcpy: the float64 fields of a packed record are not 8-byte aligned)
+        memcpy(l, r + o_loc, sizeof(l)); memcpy(v, r + o_vel, sizeof(v)); memcpy(w, r + o_wp, sizeof(w));
+        memcpy(&rad, r + o_rad, sizeof(rad)); memcpy(&t, r + o_ts, sizeof(t));
+        x[i] = (float)l[0]; y[i] = (float)l[1]; z[i] = (float)l[2];
+        vx[i] = (float)v[0]; vy[i] = (float)v[1]; vz[i] = (float)v[2];
+        wx[i] = (float)w[0]; wy[i] = (float)w[1]; ts[i] = (float)t; rr[i] = (float)rad;
+        cm[i] = (border_off && border_off[i]) ? 1 : 0;
+        if (i == 0) { z0 = z_lo = z_hi = l[2]; }
+        flat = flat && l[2] == z0 && v[2] == 0.0;
+        z_lo = std::fmin(z_lo, l[2]); z_hi = std::fmax(z_hi, l[2]); vz_max = std::fmax(vz_max, std::fabs(v[2]));
+    }
+    // the 2-D kernels iff all z are equal and no pedestrian has a v_z (then the 3-component formulas of forces.py:74-117 and
+    // stateutils.py:18-23 reduce to them exactly) -- or, planar_tolerance >= 0, nearly so: every |z - median z| and |v_z| within it
+    // (the facade's documented deviation for walkers on almost level ground)
+    if (!flat && planar_tolerance >= 0.0f && N > 0 && vz_max <= (double)planar_tolerance && z_hi - z_lo <= 2.0 * (double)planar_tolerance) {
+        std::vector<double> zs(n);
+        for (size_t i = 0; i < n; ++i) { double l2; memcpy(&l2, base + (size_t)stride * i + o_loc + 2 * sizeof(double), sizeof(l2)); zs[i] = l2; }
+        std::sort(zs.begin(), zs.end());
+        const double med = (n & 1) ? zs[n / 2] : 0.5 * (zs[n / 2 - 1] + zs[n / 2]);        // np.median
+        flat = std::fmax(z_hi - med, med - z_lo) <= (double)planar_tolerance;
+    }
+    if (was_planar) *was_planar = flat ? 1 : 0;
+    return step_core(h, N, !flat, flags, v_out);
 }
 
 int sfm_download_state(SfmHandle* h, float* x, float* y, float* z, float* vx, float* vy, float* vz, float* wx,

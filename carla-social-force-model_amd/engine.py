@@ -81,6 +81,7 @@ class SfmEngine:
         self.n = 0
         self.shard = (0, 0)
         self.planar = True
+        self._z0 = 0.0            # a flat crowd's common z (the device only holds x / y of a planar crowd)
         if stream is not None:
             self.set_stream(stream)
 
@@ -264,6 +265,31 @@ class SfmEngine:
         self.n = n
         self.shard = (0, n)
 
+    def step_records(self, records, n, border_off, v_out, planar_tolerance=None, integrate=False, redraw=False):
+        """One host-in-the-loop tick straight from the pedestrian records (sfm_step_records, ABI 5): ``records`` the structured array
+        PedestrianState keeps (fields loc, vel, next_waypoint float64 (3,), radius, target_speed float64; any stride), its first ``n`` rows;
+        ``border_off`` bool / uint8 (n,) or None; v' into ``v_out`` float32 (n, 3).  Returns whether the planar bodies ran."""
+        key = (id(records), id(v_out.base))
+        if getattr(self, "_rec_key", None) != key:
+            f = records.dtype.fields
+            off = np.array([f[k][1] for k in ("loc", "vel", "next_waypoint", "radius", "target_speed")], dtype=np.int32)
+            for k in ("loc", "vel", "next_waypoint", "radius", "target_speed"):
+                if f[k][0].base != np.dtype(np.float64):
+                    raise TypeError(f"record field {k!r} must be float64")
+            # (the arrays themselves are kept: an id can only be trusted while its object is alive)
+            self._rec_key, self._rec_ptrs = key, (records.ctypes.data, int(records.strides[0]), off, off.ctypes.data, fptr(v_out), C.c_int32(0), records, v_out.base)
+        p_rec, stride, _off, p_off, p_out, flag = self._rec_ptrs[:6]
+        rc = self._lib.sfm_step_records(self._h, n, p_rec, stride, p_off, None if border_off is None else border_off.ctypes.data,
+                                        -1.0 if planar_tolerance is None else float(planar_tolerance),
+                                        (_lib.TICK_INTEGRATE if integrate else 0) | (_lib.TICK_REDRAW_WAYPOINTS if redraw else 0), p_out, C.byref(flag))
+        if rc != 0:
+            self._check(rc, "sfm_step_records")
+        self.n = n
+        self.shard = (0, n)
+        self.planar = bool(flag.value)
+        self._z0 = None
+        return self.planar
+
     def set_shard(self, i_begin, i_end):
         self._check(self._lib.sfm_set_shard(self._h, int(i_begin), int(i_end)), "sfm_set_shard")
         self.shard = (int(i_begin), int(i_end))
@@ -349,6 +375,8 @@ class SfmEngine:
         self._check(self._lib.sfm_download_state(self._h, *(fptr(a[k]) for k in ("x", "y", "z", "vx", "vy", "vz", "wx", "wy"))),
                     "sfm_download_state")
         if self.planar:      # rows are in the library's own order: the owned pedestrians are the ones a value came back for
+            if self._z0 is None:      # (last upload was sfm_step_records: the flat crowd's z is in the caller's records)
+                self._z0 = float(self._rec_ptrs[6]["loc"][0, 2]) if self.n else 0.0
             a["z"][~np.isnan(a["x"])] = np.float32(self._z0)
         loc = np.stack([a["x"], a["y"], a["z"]], axis=1).astype(np.float64)
         vel = np.stack([a["vx"], a["vy"], a["vz"]], axis=1).astype(np.float64)

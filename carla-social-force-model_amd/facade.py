@@ -86,6 +86,9 @@ class PedestrianSimulation:
         self._rows = np.empty((16, 9), dtype=np.float32)
         self._zvz = np.empty((16, 2), dtype=np.float32)
         self._vout = np.empty((16, 3), dtype=np.float32)
+        # ... or, with a library of ABI >= 5, straight from the records (sfm_step_records); SFM_FACADE_RECORDS=0 keeps the packed block
+        import os
+        self._use_records = self.engine._lib.sfm_abi_version() >= 5 and os.environ.get("SFM_FACADE_RECORDS", "1") != "0"
 
     def init_forces(self):
         """dict force name -> FusedForce in the reference's order (pedestrian_simulation.py:37-48); uploads
@@ -139,6 +142,11 @@ class PedestrianSimulation:
         if n > len(self._rows):
             cap = max(n, 2 * len(self._rows))
             self._rows, self._zvz, self._vout = (np.empty((cap, w), dtype=np.float32) for w in (9, 2, 3))
+        if self._use_records:
+            # ABI 5: the library gathers the five fields out of the records itself (and decides planar / 3-D the same way as below)
+            vout = self._vout[:n]
+            self.engine.step_records(peds._buf, n, peds.crossing_mask(), vout, self.planar_tolerance)
+            return vout
         rows = peds.pack_rows(self._rows)
         s = peds.state
         z, vz = s['loc'][:, 2], s['vel'][:, 2]

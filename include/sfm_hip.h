@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SFM_ABI_VERSION 4   /* 2: + sfm_tick_begin / sfm_tick_end, sfm_set_partition, sfm_get_pair_work; 3: + sfm_set_timing; 4: + sfm_step_packed, sfm_set_dynamic_obstacles_packed (additions only) */
+#define SFM_ABI_VERSION 5   /* 2: + sfm_tick_begin / sfm_tick_end, sfm_set_partition, sfm_get_pair_work; 3: + sfm_set_timing; 4: + sfm_step_packed, sfm_set_dynamic_obstacles_packed; 5: + sfm_step_records (additions only) */
 
 typedef struct SfmHandle SfmHandle;
 
@@ -207,6 +207,13 @@ int sfm_download_velocities(SfmHandle* h, float* vx, float* vy, float* vz);
  *   v_out [N][3]  {vx', vy', vz'}, the caller's index order.
  * Errors as the three calls it stands for. */
 int sfm_step_packed(SfmHandle* h, int N, const float* rows, const float* zvz, uint32_t flags, float* v_out);
+/* The same straight from the caller's pedestrian RECORDS (ABI 5): PedestrianState's structured-array rows (pedestrian_state.py:17-23),
+ * `stride` bytes apart, float64 fields at byte offsets field_offsets[5] = {loc[3], vel[3], next_waypoint[3], radius, target_speed} (they
+ * need not be aligned); border_off [N] = 1 where the border force is off (modes CROSSING_ROAD / ROAD_TO_SIDEWALK, forces.py:176-177),
+ * or NULL.  The crowd is taken as planar iff all z are equal and every v_z is 0 -- or, planar_tolerance >= 0, iff the spread of z and
+ * every |v_z| are within it; *was_planar (may be NULL) says which bodies ran.  v_out [N][3] as above. */
+int sfm_step_records(SfmHandle* h, int N, const void* records, int64_t stride, const int32_t* field_offsets, const uint8_t* border_off,
+                     float planar_tolerance, uint32_t flags, float* v_out, int32_t* was_planar);
 
 /* Whole numeric state of the shard rows (any pointer may be NULL to skip that column). */
 int sfm_download_state(SfmHandle* h, float* x, float* y, float* z, float* vx, float* vy, float* vz,

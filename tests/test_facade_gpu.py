@@ -228,3 +228,61 @@ def test_mode_changes_between_ticks_are_honoured():
             t += c.dt
     finally:
         sim.close()
+
+
+def test_step_from_the_records_is_the_packed_step(monkeypatch):
+    """sfm_step_records (ABI 5) gathers loc / vel / next_waypoint / radius / target_speed out of PedestrianState's 132-byte records
+    (pedestrian_state.py:17-23) inside the library; sfm_step_packed gets the same numbers from six NumPy assignments.  Same v', bit
+    for bit: a flat crowd, walkers on uneven ground, the planar_tolerance deviation, border-force-off rows -- through the engine, and the
+    facade with either path."""
+    from carla_social_force_model_amd import scenarios
+    from carla_social_force_model_amd.config import default_sfm_config
+    from carla_social_force_model_amd.engine import SfmEngine
+    from carla_social_force_model_amd.host_state import PED_STATE_DTYPE
+
+    for n, z_spread, tol in ((37, 0.0, None), (200, 0.4, None), (200, 0.004, 0.01), (130, 0.004, 0.001)):
+        sc = scenarios.make_scenario(n, 900 + n, n_borders=12, n_static=6, n_dynamic=3, z_spread=z_spread)
+        rec = np.zeros(n + 5, dtype=PED_STATE_DTYPE)              # (capacity beyond n, like the facade's growable buffer)
+        rec['loc'][:n], rec['vel'][:n], rec['next_waypoint'][:n] = sc.loc, sc.vel, sc.waypoint
+        rec['radius'][:n], rec['target_speed'][:n] = sc.radius, sc.target_speed
+        off = np.zeros(n, dtype=bool)
+        off[::7] = True
+        cfg = default_sfm_config(scenarios.ALL_FORCES)
+        a, b = SfmEngine(cfg, 0.05), SfmEngine(cfg, 0.05)
+        try:
+            for e in (a, b):
+                e.set_borders(sc.borders, sc.border_centers, sc.border_lengths)
+                e.set_static_obstacles(sc.static_obstacles)
+                e.set_dynamic_obstacles(sc.dynamic_obstacles, sc.dynamic_vel)
+            va, vb = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32)
+            planar = a.step_records(rec, n, off, va, tol)
+            z, vz = sc.loc[:, 2], sc.vel[:, 2]
+            flat = bool((z == z[0]).all()) and not bool(vz.any())
+            if not flat and tol is not None:
+                flat = bool(np.max(np.abs(z - np.median(z))) <= tol and np.max(np.abs(vz)) <= tol)
+            assert planar == flat, (n, z_spread, tol)
+            rows = np.zeros((n, 9), np.float32)
+            rows[:, 0:2], rows[:, 2:4], rows[:, 4:6] = sc.loc[:, :2], sc.vel[:, :2], sc.waypoint[:, :2]
+            rows[:, 6], rows[:, 7], rows[:, 8] = sc.target_speed, sc.radius, off
+            zvz = None if flat else np.ascontiguousarray(np.stack([z, vz], axis=1), dtype=np.float32)
+            b.step_packed(rows, zvz, vb)
+            b._z0 = float(z[0])                                       # (what the facade does beside sfm_step_packed)
+            assert np.array_equal(va, vb), (n, z_spread, tol)
+            la, _, _ = a.state()
+            assert np.array_equal(la, b.state()[0]) or not flat       # (a flat crowd's z comes back from the records)
+        finally:
+            a.close(); b.close()
+
+    c = gio.Case(CASES["all_s0_n64"])
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("SFM_FACADE_RECORDS", flag)
+        sim = _build(c)
+        try:
+            assert sim._use_records == (flag == "1")
+            for k in range(3):
+                sim.tick(0.05 * k)
+            out[flag] = np.array(sim.get_new_velocities()['vel'])
+        finally:
+            sim.close()
+    assert np.array_equal(out["1"], out["0"])

@@ -45,11 +45,16 @@ for quiet, (n, nb, ns, nd) in enumerate(((64, 40, 16, 4), (20, 8, 4, 2), (64, 40
     parts["update_dynamic_obstacles (staging only)"] = timed(lambda: sim.update_dynamic_obstacles(dyn))
     sim._staged.clear()
     parts["apply_current_mode + idle FSMs + kerb list"] = timed(lambda: (peds.apply_current_mode(), [f.tick(0.0) for f in tuple(peds.watch.idle)]))
-    parts["pack_rows (132-B records -> one fp32 block) + flatness test"] = timed(lambda: (peds.pack_rows(sim._rows), bool((peds.state['loc'][:, 2] == 0).all()), bool(peds.state['vel'][:, 2].any())))
+    if not sim._use_records:
+        parts["pack_rows (132-B records -> one fp32 block) + flatness test"] = timed(lambda: (peds.pack_rows(sim._rows), bool((peds.state['loc'][:, 2] == 0).all()), bool(peds.state['vel'][:, 2].any())))
     parts["engine.set_dynamic_vehicles (1 concatenate, 2 writes, 1 call; staged for the upload's launch)"] = timed(lambda: eng.set_dynamic_vehicles(dyn[1], dyn[5], dyn[3]))
     rows = peds.pack_rows(sim._rows)
     vout = sim._vout[:n]
-    parts["engine.step_packed (upload + tick + v' download, 1 call)"] = timed(lambda: eng.step_packed(rows, None, vout))
+    if sim._use_records:
+        mask = peds.crossing_mask()
+        parts["engine.step_records (fields gathered from the 132-B records, upload + tick + v' download, 1 call)"] = timed(lambda: eng.step_records(peds._buf, n, mask, vout, None))
+    else:
+        parts["engine.step_packed (upload + tick + v' download, 1 call)"] = timed(lambda: eng.step_packed(rows, None, vout))
     parts["publish v' into state['vel'] (the [['id','vel']] view)"] = timed(lambda: sim._publish(vout))
     if quiet == 0:
         sim.close()
